@@ -1,0 +1,234 @@
+// GEMM family of the transformer blocks: Linear forward (NT), dgrad (NN), wgrad (TN) with fused epilogues.
+// This file holds (1) the exact-fp32 / any-layout tiled kernel used by the MAE_F32 parity path and as the
+// shape fallback, and (2) the dispatch to the bf16 MFMA kernels (k_gemm_mfma.hip) for the throughput path.
+// Reference behaviour: torch.nn.Linear inside timm Attention.qkv/.proj, Mlp.fc1/.fc2, lightly
+// decoder_embed/decoder_pred and the patch-embed conv viewed as a Linear over (c,py,px) patch vectors.
+#include "kernels.h"
+#include "gemm_mfma.h"
+
+namespace mae {
+
+// ---------------------------------------------------------------------------------------------------
+// epilogue shared by every GEMM kernel: (m, n, acc) -> stores
+// ---------------------------------------------------------------------------------------------------
+template <class TO>
+struct EpiDev {
+  int mode;
+  const float* bias;
+  const void* aux;
+  TO* out;
+  TO* out2;
+  int64_t ld;  // leading dimension of out/out2/aux
+  __device__ __forceinline__ void apply(int64_t m, int n, float acc) const {
+    const int64_t o = m * ld + n;
+    if (bias) acc += bias[n];
+    if (mode == MAE_EPI_NONE) {
+      out[o] = from_f<TO>(acc);
+    } else if (mode == MAE_EPI_GELU) {
+      const TO pre = from_f<TO>(acc);
+      out[o] = pre;
+      out2[o] = from_f<TO>(gelu_erf(to_f(pre)));  // activation of the value as stored (bf16-rounded in bf16 mode)
+    } else if (mode == MAE_EPI_RESID) {
+      out[o] = from_f<TO>(acc + reinterpret_cast<const float*>(aux)[o]);
+    } else {  // MAE_EPI_DGELU
+      out[o] = from_f<TO>(acc * gelu_erf_grad(to_f(reinterpret_cast<const TO*>(aux)[o])));
+    }
+  }
+};
+
+// C[m][n] = sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn];  64x64 tile, 16-deep steps, 4x4 outputs per thread.
+// ATOMIC: split-K over gridDim.z with fp32 atomicAdd into a zeroed `out` (wgrad of the fallback path).
+template <class TI, class TO, bool ATOMIC>
+__global__ void __launch_bounds__(256) gemm_generic_kernel(const TI* __restrict__ A, int64_t sam, int64_t sak,
+                                                           const TI* __restrict__ Bm, int64_t sbk, int64_t sbn, int64_t M,
+                                                           int N, int64_t K, int64_t k_chunk, EpiDev<TO> epi) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int64_t m0 = (int64_t)blockIdx.y * 64;
+  const int n0 = blockIdx.x * 64;
+  const int64_t kbeg = (int64_t)blockIdx.z * k_chunk;
+  const int64_t kend = kbeg + k_chunk < K ? kbeg + k_chunk : K;
+  float acc[4][4] = {};
+  for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i;
+      int mm, kk;
+      if (sak == 1) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+      const int64_t gm = m0 + mm, gk = k0 + kk;
+      As[kk][mm] = (gm < M && gk < kend) ? to_f(A[gm * sam + gk * sak]) : 0.f;
+      int nn, k2;
+      if (sbn == 1) { nn = e & 63; k2 = e >> 6; } else { k2 = e & 15; nn = e >> 4; }
+      const int gn = n0 + nn;
+      const int64_t gk2 = k0 + k2;
+      Bs[k2][nn] = (gn < N && gk2 < kend) ? to_f(Bm[gk2 * sbk + (int64_t)gn * sbn]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t gm = m0 + ty * 4 + i;
+    if (gm >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gn = n0 + tx * 4 + j;
+      if (gn >= N) continue;
+      if (ATOMIC) atomicAdd(reinterpret_cast<float*>(epi.out) + gm * epi.ld + gn, acc[i][j]);
+      else epi.apply(gm, gn, acc[i][j]);
+    }
+  }
+}
+
+template <class TI, class TO>
+static int run_generic(const void* A, int64_t sam, int64_t sak, const void* Bm, int64_t sbk, int64_t sbn, int64_t M, int N,
+                       int64_t K, const Epi& e, hipStream_t s) {
+  EpiDev<TO> d{e.mode, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, (int64_t)N};
+  MAE_REQUIRE(cdiv(M, 64) <= 65535, "gemm: M too large for the fallback kernel grid");
+  dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64), 1);
+  hipLaunchKernelGGL((gemm_generic_kernel<TI, TO, false>), grid, dim3(256), 0, s, (const TI*)A, sam, sak, (const TI*)Bm, sbk,
+                     sbn, M, N, K, K, d);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+static int check_epi(const Epi& e, int dt, const char* who) {
+  MAE_REQUIRE(e.out, "%s: null output", who);
+  MAE_REQUIRE(e.mode >= MAE_EPI_NONE && e.mode <= MAE_EPI_DGELU, "%s: unknown epilogue %d", who, e.mode);
+  MAE_REQUIRE(e.mode != MAE_EPI_GELU || e.out2, "%s: GELU epilogue needs out2", who);
+  MAE_REQUIRE((e.mode != MAE_EPI_RESID && e.mode != MAE_EPI_DGELU) || e.aux, "%s: epilogue needs aux", who);
+  MAE_REQUIRE(e.mode != MAE_EPI_RESID || e.out_dt == MAE_F32, "%s: RESID epilogue writes fp32", who);
+  MAE_REQUIRE(dt == MAE_F32 || dt == MAE_BF16, "%s: bad dtype %d", who, dt);
+  MAE_REQUIRE(!(dt == MAE_F32 && e.out_dt == MAE_BF16), "%s: fp32 operands with bf16 output unsupported", who);
+  return 0;
+}
+
+int launch_linear_fwd(const void* A, const void* W, int64_t M, int N, int K, int dt, const Epi& e, hipStream_t s) {
+  MAE_REQUIRE(A && W && M > 0 && N > 0 && K > 0, "linear_fwd: bad arguments");
+  MAE_TRY(check_epi(e, dt, "linear_fwd"));
+  if (dt == MAE_BF16) {
+    const int r = mfma_linear_fwd((const bf16*)A, (const bf16*)W, M, N, K, e, s);
+    if (r != MFMA_UNSUPPORTED) return r;
+    if (e.out_dt == MAE_BF16) return run_generic<bf16, bf16>(A, K, 1, W, 1, K, M, N, K, e, s);
+    return run_generic<bf16, float>(A, K, 1, W, 1, K, M, N, K, e, s);
+  }
+  return run_generic<float, float>(A, K, 1, W, 1, K, M, N, K, e, s);
+}
+
+int launch_linear_dgrad(const void* dY, const void* W, int64_t M, int N, int K, int dt, const Epi& e, hipStream_t s) {
+  MAE_REQUIRE(dY && W && M > 0 && N > 0 && K > 0, "linear_dgrad: bad arguments");
+  MAE_TRY(check_epi(e, dt, "linear_dgrad"));
+  MAE_REQUIRE(e.mode == MAE_EPI_NONE || e.mode == MAE_EPI_DGELU, "linear_dgrad: epilogue must be NONE or DGELU");
+  // dX[m][k] = sum_n dY[m][n] W[n][k]: reduction length N, output width K
+  if (dt == MAE_BF16) {
+    if (e.out_dt == MAE_BF16) return run_generic<bf16, bf16>(dY, N, 1, W, K, 1, M, K, N, e, s);
+    return run_generic<bf16, float>(dY, N, 1, W, K, 1, M, K, N, e, s);
+  }
+  return run_generic<float, float>(dY, N, 1, W, K, 1, M, K, N, e, s);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bias gradient: db[n] = sum_m dY[m][n]; two stages, deterministic
+// ---------------------------------------------------------------------------------------------------
+constexpr int COLSUM_BLOCKS = 256;
+
+template <class T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ dY, int64_t M, int N, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float red[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + lane * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+    for (int64_t r = blockIdx.x * 4ll + wave; r < M; r += (int64_t)gridDim.x * 4) acc += load4(dY + r * N + c);
+  }
+  store4(&red[wave][lane * 4], acc);
+  __syncthreads();
+  if (wave == 0 && c < N) {
+    acc = load4(&red[0][lane * 4]) + load4(&red[1][lane * 4]) + load4(&red[2][lane * 4]) + load4(&red[3][lane * 4]);
+    store4(partial + (int64_t)blockIdx.x * N + c, acc);
+  }
+}
+
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int nb, int N, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float acc = 0.f;
+  for (int i = 0; i < nb; ++i) acc += partial[(int64_t)i * N + c];
+  out[c] = acc;
+}
+
+int64_t linear_wgrad_scratch_bytes(int64_t M, int N, int K) {
+  return round_up((int64_t)COLSUM_BLOCKS * N * 4, 256) + mfma_wgrad_scratch_bytes(M, N, K);
+}
+
+int launch_linear_wgrad(const void* dY, const void* A, int64_t M, int N, int K, int dt, float* dW, float* db, void* scratch,
+                        hipStream_t s) {
+  MAE_REQUIRE(dY && A && dW && M > 0 && N > 0 && K > 0, "linear_wgrad: bad arguments");
+  MAE_REQUIRE(dt == MAE_F32 || dt == MAE_BF16, "linear_wgrad: bad dtype");
+  MAE_REQUIRE(!db || (scratch && N % 4 == 0), "linear_wgrad: bias gradient needs scratch and N %% 4 == 0");
+  if (db) {
+    const int G = (int)std::min<int64_t>(cdiv(M, 4), COLSUM_BLOCKS);
+    dim3 grid(G, (unsigned)cdiv(N, 256));
+    if (dt == MAE_BF16) hipLaunchKernelGGL((colsum_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)dY, M, N, (float*)scratch);
+    else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dY, M, N, (float*)scratch);
+    MAE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, (const float*)scratch, G, N, db);
+    MAE_LAUNCH_CHECK();
+  }
+  if (dt == MAE_BF16) {
+    void* slab = scratch ? (char*)scratch + round_up((int64_t)COLSUM_BLOCKS * N * 4, 256) : nullptr;
+    const int r = mfma_linear_wgrad((const bf16*)dY, (const bf16*)A, M, N, K, dW, slab, s);
+    if (r != MFMA_UNSUPPORTED) return r;
+  }
+  // fallback: dW[n][k] = sum_m dY[m*N + n] * A[m*K + k]; reduction over M, split across gridDim.z when long
+  const int64_t chunk = M <= 4096 ? M : 2048;
+  const int nz = (int)cdiv(M, chunk);
+  MAE_REQUIRE(nz <= 65535, "linear_wgrad: reduction too long for the fallback kernel");
+  EpiDev<float> d{MAE_EPI_NONE, nullptr, nullptr, dW, nullptr, (int64_t)K};
+  dim3 grid((unsigned)cdiv(K, 64), (unsigned)cdiv(N, 64), nz);
+  if (nz == 1) {
+    if (dt == MAE_BF16)
+      hipLaunchKernelGGL((gemm_generic_kernel<bf16, float, false>), grid, dim3(256), 0, s, (const bf16*)dY, (int64_t)1, (int64_t)N, (const bf16*)A, (int64_t)K, (int64_t)1, (int64_t)N, K, M, chunk, d);
+    else
+      hipLaunchKernelGGL((gemm_generic_kernel<float, float, false>), grid, dim3(256), 0, s, (const float*)dY, (int64_t)1, (int64_t)N, (const float*)A, (int64_t)K, (int64_t)1, (int64_t)N, K, M, chunk, d);
+  } else {
+    MAE_HIP(hipMemsetAsync(dW, 0, (size_t)N * K * sizeof(float), s));
+    if (dt == MAE_BF16)
+      hipLaunchKernelGGL((gemm_generic_kernel<bf16, float, true>), grid, dim3(256), 0, s, (const bf16*)dY, (int64_t)1, (int64_t)N, (const bf16*)A, (int64_t)K, (int64_t)1, (int64_t)N, K, M, chunk, d);
+    else
+      hipLaunchKernelGGL((gemm_generic_kernel<float, float, true>), grid, dim3(256), 0, s, (const float*)dY, (int64_t)1, (int64_t)N, (const float*)A, (int64_t)K, (int64_t)1, (int64_t)N, K, M, chunk, d);
+  }
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mae
+
+extern "C" int mae_linear_fwd(const void* A, const void* W, const float* bias, int64_t M, int32_t N, int32_t K,
+                              int32_t dtype, int32_t epilogue, int32_t out_dtype, void* out, void* out2,
+                              const void* aux_or_resid, void* stream) {
+  mae::Epi e;
+  e.mode = epilogue; e.bias = bias; e.aux = aux_or_resid; e.out = out; e.out2 = out2; e.out_dt = out_dtype;
+  return mae::launch_linear_fwd(A, W, M, N, K, dtype, e, (hipStream_t)stream);
+}
+
+extern "C" int64_t mae_linear_wgrad_scratch_bytes(int64_t M, int32_t N, int32_t K) {
+  return mae::linear_wgrad_scratch_bytes(M, N, K);
+}
+
+extern "C" int mae_linear_wgrad(const void* dY, const void* A, int64_t M, int32_t N, int32_t K, int32_t dtype, float* dW,
+                                float* db, void* scratch, void* stream) {
+  return mae::launch_linear_wgrad(dY, A, M, N, K, dtype, dW, db, scratch, (hipStream_t)stream);
+}

@@ -1,0 +1,189 @@
+// LayerNorm(eps) forward / backward over fp32 residual-stream rows; one wave (64 lanes) per row, the row held
+// in registers, mean/variance by wavefront shuffles.  HBM-bound: fwd reads 4*D B/row, writes sizeof(T)*D.
+// Reference behaviour: torch.nn.LayerNorm(dim, eps=1e-6) as timm VisionTransformer / lightly MAEDecoderTIMM
+// instantiate it (norm1/norm2/norm/decoder_norm), computed in fp32 (autocast keeps layer_norm in fp32).
+#include "kernels.h"
+
+namespace mae {
+
+// NV = float4 vectors per lane: covers dim <= 256*NV
+template <class T, int NV>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ row_map,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, int64_t rows, int dim, T* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63;
+  const int D4 = dim >> 2;
+  const float inv_d = 1.0f / (float)dim;
+  for (int64_t r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+    const int64_t src = row_map ? (int64_t)row_map[r] : r;
+    const float* px = x + src * dim;
+    f32x4 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        v[i] = load4(px + c * 4);
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+      } else {
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float mean = wave_sum(sum) * inv_d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        const f32x4 d = v[i] - mean;
+        sq += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+      }
+    }
+    const float var = wave_sum(sq) * inv_d;
+    const float rstd = rsqrtf(var + eps);
+    T* py = y + r * dim;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        const f32x4 o = (v[i] - mean) * rstd * load4(gamma + c * 4) + load4(beta + c * 4);
+        store4(py + c * 4, o);
+      }
+    }
+    if (lane == 0) {
+      mean_out[r] = mean;
+      rstd_out[r] = rstd;
+    }
+  }
+}
+
+int launch_layernorm_fwd(const float* x, const int32_t* row_map, const float* gamma, const float* beta, float eps,
+                         int64_t rows, int dim, int y_dt, void* y, float* mean, float* rstd, hipStream_t s) {
+  MAE_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0, "layernorm_fwd: null buffer");
+  MAE_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= 1024, "layernorm: dim %d must be a multiple of 4 in [4, 1024]", dim);
+  const int nv = (int)cdiv(dim / 4, 64);
+  const int grid = (int)std::min<int64_t>(cdiv(rows, 4), 256 * 32);
+#define LN(T, NV) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV>), dim3(grid), dim3(256), 0, s, x, row_map, gamma, beta, eps, rows, dim, (T*)y, mean, rstd)
+#define LN_NV(T) switch (nv) { case 1: LN(T, 1); break; case 2: LN(T, 2); break; case 3: LN(T, 3); break; default: LN(T, 4); }
+  if (y_dt == MAE_BF16) { LN_NV(bf16) } else { LN_NV(float) }
+#undef LN_NV
+#undef LN
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// Backward.  xhat = (x-mean)*rstd, g = dy*gamma:
+//   dx = rstd * (g - mean(g) - xhat*mean(g*xhat));  dgamma = sum_rows dy*xhat;  dbeta = sum_rows dy
+// Each wave keeps per-lane column partials of dgamma/dbeta across the rows it walks; the block's 4 waves are
+// combined through LDS into partial[block][2][dim]; a second kernel adds the blocks in order (deterministic).
+template <class T, int NV>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+                                                            const int32_t* __restrict__ row_map,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int64_t rows, int dim,
+                                                            int accumulate, float* __restrict__ dx_io, T* __restrict__ dx_copy,
+                                                            float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][2][dim]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D4 = dim >> 2;
+  const float inv_d = 1.0f / (float)dim;
+  f32x4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    gam[i] = (c < D4) ? load4(gamma + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t r = blockIdx.x * 4ll + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+    const int64_t src = row_map ? (int64_t)row_map[r] : r;
+    const float mu = mean[r], rs = rstd[r];
+    f32x4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        const f32x4 d = load4(dy + r * dim + c * 4);
+        xh[i] = (load4(x + src * dim + c * 4) - mu) * rs;
+        g[i] = d * gam[i];
+        dg[i] += d * xh[i];
+        db[i] += d;
+        s1 += g[i][0] + g[i][1] + g[i][2] + g[i][3];
+        s2 += g[i][0] * xh[i][0] + g[i][1] * xh[i][1] + g[i][2] * xh[i][2] + g[i][3] * xh[i][3];
+      }
+    }
+    s1 = wave_sum(s1) * inv_d;
+    s2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D4) {
+        f32x4 d = (g[i] - s1 - xh[i] * s2) * rs;
+        float* pd = dx_io + src * dim + c * 4;
+        if (accumulate) d += load4(pd);
+        store4(pd, d);
+        if (dx_copy) store4(dx_copy + src * dim + c * 4, d);
+      }
+    }
+  }
+  // block reduce of the column partials
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D4) {
+      store4(red + (wave * 2 + 0) * dim + c * 4, dg[i]);
+      store4(red + (wave * 2 + 1) * dim + c * 4, db[i]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * dim; c += 256) {
+    const float v = red[c] + red[2 * dim + c] + red[4 * dim + c] + red[6 * dim + c];
+    partial[(int64_t)blockIdx.x * 2 * dim + c] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) layernorm_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int dim,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * dim) return;
+  float acc = 0.f;
+  for (int i = 0; i < nb; ++i) acc += partial[(int64_t)i * 2 * dim + c];
+  if (c < dim) dgamma[c] = acc; else dbeta[c - dim] = acc;
+}
+
+int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_t* row_map, const float* gamma,
+                         const float* mean, const float* rstd, int64_t rows, int dim, int accumulate, float* dx_io,
+                         void* dx_copy, float* dgamma, float* dbeta, float* partial, hipStream_t s) {
+  MAE_REQUIRE(dy && x && gamma && mean && rstd && dx_io && dgamma && dbeta && partial && rows > 0, "layernorm_bwd: null buffer");
+  MAE_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= 1024, "layernorm: dim %d must be a multiple of 4 in [4, 1024]", dim);
+  const int nv = (int)cdiv(dim / 4, 64);
+  const int grid = (int)std::min<int64_t>(cdiv(rows, 4), LN_BWD_MAX_BLOCKS);
+  const size_t lds = (size_t)8 * dim * sizeof(float);
+#define LNB(T, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NV>), dim3(grid), dim3(256), lds, s, (const T*)dy, x, row_map, gamma, mean, rstd, rows, dim, accumulate, dx_io, (T*)dx_copy, partial)
+#define LNB_NV(T) switch (nv) { case 1: LNB(T, 1); break; case 2: LNB(T, 2); break; case 3: LNB(T, 3); break; default: LNB(T, 4); }
+  if (dy_dt == MAE_BF16) { LNB_NV(bf16) } else { LNB_NV(float) }
+#undef LNB_NV
+#undef LNB
+  MAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((int)cdiv(2 * dim, 256)), dim3(256), 0, s, partial, grid, dim, dgamma, dbeta);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mae
+
+extern "C" int mae_layernorm_fwd(const float* x, const int32_t* row_map, const float* gamma, const float* beta, float eps,
+                                 int64_t rows, int32_t dim, int32_t y_dtype, void* y, float* mean, float* rstd,
+                                 void* stream) {
+  return mae::launch_layernorm_fwd(x, row_map, gamma, beta, eps, rows, dim, y_dtype, y, mean, rstd, (hipStream_t)stream);
+}
+
+extern "C" int mae_layernorm_bwd(const void* dy, int32_t dy_dtype, const float* x, const int32_t* row_map,
+                                 const float* gamma, const float* mean, const float* rstd, int64_t rows, int32_t dim,
+                                 int32_t accumulate, float* dx_io, void* dx_copy, float* dgamma, float* dbeta,
+                                 float* partial, void* stream) {
+  return mae::launch_layernorm_bwd(dy, dy_dtype, x, row_map, gamma, mean, rstd, rows, dim, accumulate, dx_io, dx_copy,
+                                   dgamma, dbeta, partial, (hipStream_t)stream);
+}

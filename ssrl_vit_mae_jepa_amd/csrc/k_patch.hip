@@ -1,0 +1,305 @@
+// Pixel <-> token data movement: visible-patch gather (im2col of the kept patches only), token assembly
+// (cls / position table), decoder scatter with mask tokens, target patchify-gather.  All HBM-bound.
+// Reference behaviour:
+//   gather_patches + patch GEMM + assemble_visible == timm PatchEmbed conv (k = s = patch) -> cat(cls) -> +pos_embed
+//     -> gather(idx_keep)           (lightly MaskedVisionTransformerTIMM.preprocess, via src/models/mae.py:55)
+//   decoder_assemble == repeat_token(mask_token) -> set_at_index(idx_keep, x_decode) -> + decoder_pos_embed
+//                                   (src/models/mae.py:61-71)
+//   patchify_gather == utils.patchify + get_at_index(clamp(idx_mask-1, 0))   (src/models/mae.py:90-92)
+#include "kernels.h"
+
+namespace mae {
+
+// ---------------------------------------------------------------------------------------------------
+// visible-patch gather: row (b,j) <- patch tok[b][j]-1 in conv-weight order (c, py, px)
+// ---------------------------------------------------------------------------------------------------
+template <class T, int VEC>
+__global__ void __launch_bounds__(256) gather_patches_kernel(const float* __restrict__ images,
+                                                             const int32_t* __restrict__ tok, int64_t rows, int k,
+                                                             int C, int img, int p, T* __restrict__ out) {
+  const int g = img / p;
+  const int pv = p / VEC;                 // vector units per patch row
+  const int units_per_row = C * p * pv;   // per token row
+  const int64_t total = rows * units_per_row;
+  for (int64_t u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int64_t r = u / units_per_row;
+    int rem = (int)(u - r * units_per_row);
+    const int c = rem / (p * pv);
+    rem -= c * p * pv;
+    const int py = rem / pv;
+    const int px = (rem - py * pv) * VEC;
+    const int t = tok[r];
+    const int64_t b = r / k;
+    T* dst = out + r * (int64_t)(C * p * p) + (c * p + py) * p + px;
+    if (t <= 0) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dst[i] = from_f<T>(0.f);
+    } else {
+      const int n = t - 1, ph = n / g, pw = n - ph * g;
+      const float* src = images + ((b * C + c) * (int64_t)img + (ph * p + py)) * img + pw * p + px;
+      if (VEC == 4) {
+        store4(dst, load4(src));
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) dst[i] = from_f<T>(src[i]);
+      }
+    }
+  }
+}
+
+int launch_gather_patches(const float* images, const int32_t* tok, int B, int k, int C, int img, int p, int dt,
+                          void* out, hipStream_t s) {
+  MAE_REQUIRE(images && tok && out && B > 0 && k > 0, "gather_patches: bad arguments");
+  MAE_REQUIRE(p > 0 && img % p == 0, "gather_patches: image_size %d not divisible by patch_size %d", img, p);
+  const int64_t rows = (int64_t)B * k;
+  const bool vec = (p % 4 == 0) && (img % 4 == 0);
+  const int64_t units = rows * C * p * (vec ? p / 4 : p);
+  const int grid = (int)std::min<int64_t>(cdiv(units, 256), 256 * 16);
+#define GP(T, V) hipLaunchKernelGGL((gather_patches_kernel<T, V>), dim3(grid), dim3(256), 0, s, images, tok, rows, k, C, img, p, (T*)out)
+  if (dt == MAE_BF16) { if (vec) GP(bf16, 4); else GP(bf16, 1); }
+  else                { if (vec) GP(float, 4); else GP(float, 1); }
+#undef GP
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// x[r] = (t == 0 ? cls : x[r]) + pos[t], fp32 in place, D % 4 == 0
+__global__ void __launch_bounds__(256) assemble_visible_kernel(float* __restrict__ x, const int32_t* __restrict__ tok,
+                                                               const float* __restrict__ cls,
+                                                               const float* __restrict__ pos, int64_t rows, int D4) {
+  const int64_t total = rows * D4;
+  for (int64_t u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int64_t r = u / D4;
+    const int d = (int)(u - r * D4) * 4;
+    const int t = tok[r];
+    float* px = x + r * (int64_t)D4 * 4 + d;
+    f32x4 v = (t == 0) ? load4(cls + d) : load4(px);
+    v += load4(pos + (int64_t)t * D4 * 4 + d);
+    store4(px, v);
+  }
+}
+
+int launch_assemble_visible(float* x, const int32_t* tok, const float* cls, const float* pos, int64_t rows, int D,
+                            hipStream_t s) {
+  MAE_REQUIRE(x && tok && cls && pos && rows > 0 && D % 4 == 0, "assemble_visible: bad arguments (D %% 4 must be 0)");
+  const int grid = (int)std::min<int64_t>(cdiv(rows * (D / 4), 256), 256 * 16);
+  hipLaunchKernelGGL(assemble_visible_kernel, dim3(grid), dim3(256), 0, s, x, tok, cls, pos, rows, D / 4);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// Column sums of selected rows, two stages, deterministic.  Stage 1: block i sums rows i, i+G, ... into
+// partial[i][D]; stage 2: one thread per column adds the G partials in order.
+__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ partial, int G, int D,
+                                                              float* __restrict__ out) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float acc = 0.f;
+  for (int i = 0; i < G; ++i) acc += partial[(int64_t)i * D + d];
+  out[d] = acc;
+}
+
+// Row-walk helper shared by the two "split" kernels: thread (ro, c4) owns 4 columns of row offset ro; a block
+// covers RPI = 256 / (D/4) rows per iteration and G blocks stride the matrix.  Column sums of the selected rows
+// are reduced over ro in LDS and written to partial[block][D].
+constexpr int SPLIT_BLOCKS = 512;
+
+template <class T>
+__global__ void __launch_bounds__(256) visible_grad_split_kernel(const float* __restrict__ dx,
+                                                                 const int32_t* __restrict__ tok, int64_t rows, int D,
+                                                                 T* __restrict__ dtok, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [RPI][D]
+  const int D4 = D / 4, RPI = 256 / D4;
+  const int ro = threadIdx.x / D4, d0 = (threadIdx.x - ro * D4) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (ro < RPI) {
+    for (int64_t r = (int64_t)blockIdx.x * RPI + ro; r < rows; r += (int64_t)gridDim.x * RPI) {
+      const f32x4 v = load4(dx + r * D + d0);
+      const bool is_cls = tok[r] == 0;
+      if (is_cls) acc += v;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      store4(dtok + r * D + d0, is_cls ? z : v);
+    }
+    store4(red + ro * D + d0, acc);
+  }
+  __syncthreads();
+  if (ro == 0) {
+    for (int i = 1; i < RPI; ++i) acc += load4(red + i * D + d0);
+    store4(partial + (int64_t)blockIdx.x * D + d0, acc);
+  }
+}
+
+int launch_visible_grad_split(const float* dx, const int32_t* tok, int64_t rows, int D, int dt, void* dtok, float* dcls,
+                              float* partial, hipStream_t s) {
+  MAE_REQUIRE(dx && tok && dtok && dcls && partial && rows > 0 && D % 4 == 0 && D <= 1024,
+              "visible_grad_split: bad arguments (need D %% 4 == 0, D <= 1024)");
+  const int RPI = 256 / (D / 4);
+  const int G = (int)std::min<int64_t>(cdiv(rows, RPI), SPLIT_BLOCKS);
+  const size_t lds = (size_t)RPI * D * sizeof(float);
+  if (dt == MAE_BF16)
+    hipLaunchKernelGGL((visible_grad_split_kernel<bf16>), dim3(G), dim3(256), lds, s, dx, tok, rows, D, (bf16*)dtok, partial);
+  else
+    hipLaunchKernelGGL((visible_grad_split_kernel<float>), dim3(G), dim3(256), lds, s, dx, tok, rows, D, (float*)dtok, partial);
+  MAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((int)cdiv(D, 256)), dim3(256), 0, s, partial, G, D, dcls);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decoder input assembly and its adjoint
+// ---------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) decoder_assemble_kernel(const T* __restrict__ xdec,
+                                                               const int32_t* __restrict__ inv,
+                                                               const float* __restrict__ mask_token,
+                                                               const float* __restrict__ pos, int64_t rows, int k, int L,
+                                                               int D4, float* __restrict__ out) {
+  const int64_t total = rows * D4;
+  for (int64_t u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int64_t r = u / D4;  // r = b*L + t
+    const int d = (int)(u - r * D4) * 4;
+    const int64_t b = r / L;
+    const int t = (int)(r - b * L);
+    const int j = inv[r];
+    f32x4 v = (j >= 0) ? load4(xdec + (b * k + j) * (int64_t)D4 * 4 + d) : load4(mask_token + d);
+    v += load4(pos + (int64_t)t * D4 * 4 + d);
+    store4(out + r * (int64_t)D4 * 4 + d, v);
+  }
+}
+
+int launch_decoder_assemble(const void* xdec, int dt, const int32_t* inv, const float* mask_token, const float* pos,
+                            int B, int k, int L, int Dd, float* out, hipStream_t s) {
+  MAE_REQUIRE(xdec && inv && mask_token && pos && out && Dd % 4 == 0, "decoder_assemble: bad arguments");
+  const int64_t rows = (int64_t)B * L;
+  const int grid = (int)std::min<int64_t>(cdiv(rows * (Dd / 4), 256), 256 * 16);
+  if (dt == MAE_BF16)
+    hipLaunchKernelGGL((decoder_assemble_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)xdec, inv, mask_token, pos, rows, k, L, Dd / 4, out);
+  else
+    hipLaunchKernelGGL((decoder_assemble_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)xdec, inv, mask_token, pos, rows, k, L, Dd / 4, out);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) decoder_assemble_bwd_kernel(const float* __restrict__ dx,
+                                                                   const int32_t* __restrict__ inv, int64_t rows, int k,
+                                                                   int L, int D, T* __restrict__ d_xdec,
+                                                                   float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [RPI][D]
+  const int D4 = D / 4, RPI = 256 / D4;
+  const int ro = threadIdx.x / D4, d0 = (threadIdx.x - ro * D4) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (ro < RPI) {
+    for (int64_t r = (int64_t)blockIdx.x * RPI + ro; r < rows; r += (int64_t)gridDim.x * RPI) {
+      const f32x4 v = load4(dx + r * D + d0);
+      const int j = inv[r];
+      if (j < 0) {
+        acc += v;
+      } else {
+        const int64_t b = r / L;
+        store4(d_xdec + (b * k + j) * (int64_t)D + d0, v);
+      }
+    }
+    store4(red + ro * D + d0, acc);
+  }
+  __syncthreads();
+  if (ro == 0) {
+    for (int i = 1; i < RPI; ++i) acc += load4(red + i * D + d0);
+    store4(partial + (int64_t)blockIdx.x * D + d0, acc);
+  }
+}
+
+int launch_decoder_assemble_bwd(const float* dx, const int32_t* inv, const int32_t* keep, int B, int k, int L, int Dd,
+                                int dt, void* d_xdec, float* d_mask_token, float* partial, hipStream_t s) {
+  (void)keep;
+  MAE_REQUIRE(dx && inv && d_xdec && d_mask_token && partial && Dd % 4 == 0 && Dd <= 1024,
+              "decoder_assemble_bwd: bad arguments (need Dd %% 4 == 0, Dd <= 1024)");
+  const int64_t rows = (int64_t)B * L;
+  const int RPI = 256 / (Dd / 4);
+  const int G = (int)std::min<int64_t>(cdiv(rows, RPI), SPLIT_BLOCKS);
+  const size_t lds = (size_t)RPI * Dd * sizeof(float);
+  if (dt == MAE_BF16)
+    hipLaunchKernelGGL((decoder_assemble_bwd_kernel<bf16>), dim3(G), dim3(256), lds, s, dx, inv, rows, k, L, Dd, (bf16*)d_xdec, partial);
+  else
+    hipLaunchKernelGGL((decoder_assemble_bwd_kernel<float>), dim3(G), dim3(256), lds, s, dx, inv, rows, k, L, Dd, (float*)d_xdec, partial);
+  MAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((int)cdiv(Dd, 256)), dim3(256), 0, s, partial, G, Dd, d_mask_token);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pixel targets: target[(b,j)][(py*p + px)*C + c] = images[b][c][ph*p+py][pw*p+px], patch = max(mask-1, 0)
+// one thread per (row, py, px): reads C strided pixels, writes C contiguous floats
+// ---------------------------------------------------------------------------------------------------
+template <class I>
+__global__ void __launch_bounds__(256) patchify_gather_kernel(const float* __restrict__ images,
+                                                              const I* __restrict__ mask32, int64_t rows, int m,
+                                                              int C, int img, int p, float* __restrict__ target) {
+  const int g = img / p, pp = p * p;
+  const int64_t total = rows * pp;
+  for (int64_t u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int64_t r = u / pp;
+    const int q = (int)(u - r * pp);
+    const int py = q / p, px = q - py * p;
+    const int64_t b = r / m;
+    int n = (int)mask32[r] - 1;
+    n = n < 0 ? 0 : (n >= g * g ? g * g - 1 : n);
+    const int ph = n / g, pw = n - ph * g;
+    const float* src = images + (b * C * (int64_t)img + (ph * p + py)) * img + pw * p + px;
+    float* dst = target + r * (int64_t)(pp * C) + q * C;
+    for (int c = 0; c < C; ++c) dst[c] = src[(int64_t)c * img * img];
+  }
+}
+
+int launch_patchify_gather(const float* images, const int32_t* mask32, int B, int m, int C, int img, int p,
+                           float* target, hipStream_t s) {
+  MAE_REQUIRE(images && mask32 && target && B > 0 && m > 0, "patchify_gather: bad arguments");
+  MAE_REQUIRE(p > 0 && img % p == 0, "patchify: image_size %d not divisible by patch_size %d", img, p);
+  const int64_t rows = (int64_t)B * m;
+  const int grid = (int)std::min<int64_t>(cdiv(rows * p * p, 256), 256 * 16);
+  hipLaunchKernelGGL((patchify_gather_kernel<int32_t>), dim3(grid), dim3(256), 0, s, images, mask32, rows, m, C, img, p, target);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_patchify_gather_i64(const float* images, const int64_t* mask64, int B, int m, int C, int img, int p,
+                               float* target, hipStream_t s) {
+  MAE_REQUIRE(images && mask64 && target && B > 0 && m > 0, "patchify_gather: bad arguments");
+  MAE_REQUIRE(p > 0 && img % p == 0, "patchify: image_size %d not divisible by patch_size %d", img, p);
+  const int64_t rows = (int64_t)B * m;
+  const int grid = (int)std::min<int64_t>(cdiv(rows * p * p, 256), 256 * 16);
+  hipLaunchKernelGGL((patchify_gather_kernel<int64_t>), dim3(grid), dim3(256), 0, s, images, mask64, rows, m, C, img, p, target);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <class S, class D_>
+__global__ void __launch_bounds__(256) cast_kernel(const S* __restrict__ src, D_* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = from_f<D_>(to_f(src[i]));
+}
+
+int launch_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, hipStream_t s) {
+  MAE_REQUIRE(src && dst && n > 0, "cast: bad arguments");
+  const int grid = (int)std::min<int64_t>(cdiv(n, 256), 256 * 16);
+  if (src_dt == MAE_F32 && dst_dt == MAE_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16*)dst, n);
+  else if (src_dt == MAE_BF16 && dst_dt == MAE_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (float*)dst, n);
+  else if (src_dt == MAE_F32 && dst_dt == MAE_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)src, (bf16*)dst, n);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace mae
+
+extern "C" int mae_patchify_gather(const float* images, const int64_t* idx_mask, int32_t batch, int32_t in_chans,
+                                   int32_t image_size, int32_t patch_size, int32_t num_mask, float* target,
+                                   void* stream) {
+  return mae::launch_patchify_gather_i64(images, idx_mask, batch, num_mask, in_chans, image_size, patch_size, target,
+                                         (hipStream_t)stream);
+}

@@ -1,0 +1,444 @@
+"""MaskedAutoencoder: host-side mirror of the reference's ``src/models/mae.py`` (lines 12-94) over libmae_hip.so.
+
+Same constructor dicts, attributes (``mask_ratio, image_size, patch_size, in_chans, sequence_length, encoder,
+decoder``), methods (``forward``, ``forward_encoder``, ``forward_decoder``) and ``state_dict`` key names, so
+``scripts.training.pretrain_mae`` / ``src.training.mae.MAEPretrainModule`` can use it in place of the lightly/timm
+model.  PyTorch supplies device memory, streams and the autograd hook-up only; every arithmetic step of the path runs
+in the HIP library.  There is no CPU path: calling ``forward`` on CPU tensors raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Any, Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import MaeConfig, check, lib
+
+
+def _stream(device: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("libmae_hip works on device tensors only (no CPU fallback); move the tensor to cuda")
+    if not t.is_contiguous():
+        raise RuntimeError("libmae_hip needs contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Thin owner of one ``mae_engine_t`` handle plus its parameter table."""
+
+    def __init__(self, cfg: Dict[str, int], precision: str):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        self.precision = precision
+        self.act = _lib.MAE_BF16 if precision == "bf16" else _lib.MAE_F32
+        c = MaeConfig(act_dtype=self.act, mlp_ratio=4, **cfg)
+        h = C.c_void_p()
+        try:
+            check(lib.mae_engine_create(C.byref(c), C.byref(h)))
+        except _lib.MaeHipError as exc:  # constructor errors of the reference are ValueError/AssertionError
+            raise ValueError(str(exc)) from None
+        self.handle = h
+        self.arena_elems = lib.mae_engine_arena_elems(h)
+        self.trainable_elems = lib.mae_engine_trainable_elems(h)
+        self.wcache_bytes = lib.mae_engine_wcache_bytes(h)
+        self.table: List[Tuple[str, int, int, Tuple[int, ...], int]] = []
+        for i in range(lib.mae_engine_num_params(h)):
+            name, off, numel, ndim, flags = C.c_char_p(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+            shape = (C.c_int64 * 4)()
+            check(lib.mae_engine_param_info(h, i, C.byref(name), C.byref(off), C.byref(numel), C.byref(ndim), shape, C.byref(flags)))
+            self.table.append((name.value.decode(), off.value, numel.value, tuple(shape[: ndim.value]), flags.value))
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            lib.mae_engine_destroy(h)
+
+    def workspace_bytes(self, batch: int, num_keep: int) -> int:
+        n = lib.mae_engine_workspace_bytes(self.handle, batch, num_keep)
+        if n < 0:
+            raise ValueError(f"bad batch/num_keep ({batch}, {num_keep})")
+        return n
+
+    # timers -------------------------------------------------------------------------------------
+    def timers_enable(self, on: bool) -> None:
+        check(lib.mae_engine_timers_enable(self.handle, int(on)))
+
+    def timers_reset(self) -> None:
+        check(lib.mae_engine_timers_reset(self.handle))
+
+    def timers_read(self) -> Dict[str, Dict[str, float]]:
+        out = {}
+        for k in range(lib.mae_engine_timer_count(self.handle)):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            check(lib.mae_engine_timer_read(self.handle, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            out[lib.mae_engine_timer_name(self.handle, k).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        return out
+
+
+class _Node(nn.Module):
+    """Parameter holder: gives the flat arena the reference's module/attribute names."""
+
+
+class _ViT(_Node):
+    embed_dim: int = 0
+
+    def forward_features(self, images: torch.Tensor) -> torch.Tensor:
+        """timm VisionTransformer.forward_features: every token, no masking (scripts/training/train_mae.py:143)."""
+        return self._owner().forward_encoder(images, idx_keep=None)
+
+
+class _Encoder(_Node):
+    def encode(self, images: torch.Tensor, idx_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self._owner().forward_encoder(images, idx_keep=idx_keep)
+
+
+class _Decoder(_Node):
+    pass
+
+
+class _MAEFunction(torch.autograd.Function):
+    """One autograd node for the whole MaskedAutoencoder.forward: backward runs the engine's fused backward."""
+
+    @staticmethod
+    def forward(ctx, model: "MaskedAutoencoder", images, idx_keep, idx_mask, *params):
+        x_pred, target = model._run_forward(images, idx_keep, idx_mask)
+        ctx.model = model
+        ctx.generation = model._ws_generation
+        ctx.dims = (images.shape[0], idx_keep.shape[1], idx_mask.shape[1])
+        ctx.mark_non_differentiable(target)
+        return x_pred, target
+
+    @staticmethod
+    def backward(ctx, g_pred, _g_target):
+        model = ctx.model
+        if ctx.generation != model._ws_generation:
+            raise RuntimeError("MaskedAutoencoder: another forward overwrote the saved activations before backward; "
+                               "run eval/validation forwards under torch.no_grad() or after backward")
+        grads = model._run_backward(g_pred.contiguous().float(), *ctx.dims)
+        return (None, None, None, None, *grads)
+
+
+class MaskedAutoencoder(nn.Module):
+    """Masked Autoencoder (MAE) with ViT backbone -- reference API, MI355X engine."""
+
+    def __init__(self, general_cfg: Dict[str, Any], encoder_cfg: Dict[str, Any], decoder_cfg: Dict[str, Any]):
+        super().__init__()
+        # defaults exactly as the reference reads them (src/models/mae.py:23-26, 32-34, 49-51)
+        self.mask_ratio = general_cfg.get("mask_ratio", 0.75)
+        self.image_size = general_cfg.get("image_size", 96)
+        self.patch_size = general_cfg.get("patch_size", 6)
+        self.in_chans = general_cfg.get("in_chans", 3)
+        precision = general_cfg.get("engine_precision", os.environ.get("MAE_HIP_PRECISION", "bf16"))
+        cfg = dict(
+            image_size=int(self.image_size), patch_size=int(self.patch_size), in_chans=int(self.in_chans),
+            embed_dim=int(encoder_cfg.get("embed_dim", 384)), depth=int(encoder_cfg.get("depth", 12)),
+            num_heads=int(encoder_cfg.get("num_heads", 6)),
+            decoder_embed_dim=int(decoder_cfg.get("decoder_embed_dim", 512)),
+            decoder_depth=int(decoder_cfg.get("decoder_depth", 4)),
+            decoder_num_heads=int(decoder_cfg.get("decoder_num_heads", 6)),
+        )
+        self._dims = cfg
+        self._engine = Engine(cfg, precision)
+        self.sequence_length = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
+        self.patch_dim = cfg["patch_size"] ** 2 * cfg["in_chans"]
+
+        self.encoder = _Encoder()
+        self.decoder = _Decoder()
+        self.encoder.vit = _ViT()
+        self.encoder.vit.embed_dim = cfg["embed_dim"]
+        owner = [self]  # no module cycle in nn.Module registration
+        for n in (self.encoder, self.encoder.vit):
+            object.__setattr__(n, "_owner", lambda o=owner: o[0])
+
+        self._arena = torch.zeros(self._engine.arena_elems, dtype=torch.float32)
+        self._trainable: List[nn.Parameter] = []
+        self._slots: List[Tuple[nn.Parameter, int, int, Tuple[int, ...]]] = []
+        for name, off, numel, shape, flags in self._engine.table:
+            p = nn.Parameter(self._arena[off:off + numel].view(shape), requires_grad=not (flags & _lib.PARAM_FROZEN))
+            self._register(name, p)
+            self._slots.append((p, off, numel, shape))
+            if flags & _lib.PARAM_TRAINABLE:
+                self._trainable.append(p)
+        self._init_weights()
+
+        self._grad_arena: Optional[torch.Tensor] = None
+        self._wcache: Optional[torch.Tensor] = None
+        self._wcache_version = -1
+        self._workspace: Optional[torch.Tensor] = None
+        self._ws_generation = 0
+        self._scratch: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ construction helpers
+    def _register(self, dotted: str, p: nn.Parameter) -> None:
+        node: nn.Module = self
+        parts = dotted.split(".")
+        for part in parts[:-1]:
+            child = node._modules.get(part)
+            if child is None:
+                child = _Node()
+                node.add_module(part, child)
+            node = child
+        node.register_parameter(parts[-1], p)
+
+    @torch.no_grad()
+    def _init_weights(self, seed: Optional[int] = None) -> None:
+        """lightly/timm recipe: xavier-uniform Linear (patch projection on its 2-D view), zero bias, LayerNorm 1/0,
+        tokens N(0, .02), frozen 2-D sin-cos position tables (lightly MaskedVisionTransformerTIMM / MAEDecoderTIMM)."""
+        g = None
+        if seed is not None:
+            g = torch.Generator().manual_seed(seed)
+        for (name, _off, _n, shape, flags), (p, *_r) in zip(self._engine.table, self._slots):
+            if name.endswith("pos_embed"):
+                p.copy_(_sincos_2d(shape[-1], self.image_size // self.patch_size))
+            elif name.endswith("_token"):
+                p.copy_(torch.randn(shape, generator=g) * 0.02)
+            elif flags & _lib.PARAM_MATRIX:
+                fan_out, fan_in = shape[0], int(torch.tensor(shape[1:]).prod())
+                bound = (6.0 / (fan_in + fan_out)) ** 0.5
+                p.copy_((torch.rand(shape, generator=g) * 2 - 1) * bound)
+            elif name.endswith("weight"):
+                p.fill_(1.0)  # LayerNorm gain
+            else:
+                p.zero_()
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn)
+        self._reflatten()
+        return self
+
+    @torch.no_grad()
+    def _reflatten(self) -> None:
+        """After .to()/.cuda(): gather the parameters back into one flat fp32 arena on their new device."""
+        first = self._slots[0][0]
+        device = first.device
+        if first.dtype == torch.float32 and self._arena.device == device and first.data_ptr() == self._arena.data_ptr() + 4 * self._slots[0][1]:
+            return
+        arena = torch.zeros(self._engine.arena_elems, dtype=torch.float32, device=device)
+        for p, off, numel, shape in self._slots:
+            view = arena[off:off + numel].view(shape)
+            view.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = view
+            p.grad = None
+        self._arena = arena
+        self._grad_arena = self._wcache = self._workspace = self._scratch = None
+        self._wcache_version = -1
+
+    # ------------------------------------------------------------------ device-side state
+    @property
+    def engine(self) -> Engine:
+        return self._engine
+
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._arena
+
+    @property
+    def flat_grads(self) -> torch.Tensor:
+        if self._grad_arena is None or self._grad_arena.device != self._arena.device:
+            self._grad_arena = torch.zeros(self._engine.trainable_elems, dtype=torch.float32, device=self._arena.device)
+        return self._grad_arena
+
+    def _require_cuda(self) -> torch.device:
+        dev = self._arena.device
+        if dev.type != "cuda":
+            raise RuntimeError("MaskedAutoencoder runs on MI355X only: call .cuda() first (there is no CPU fallback)")
+        return dev
+
+    def _params_version(self) -> int:
+        return sum(p._version for p, *_ in self._slots)
+
+    def mark_weights_fresh(self) -> None:
+        self._wcache_version = self._params_version()
+
+    def _weights(self) -> Optional[torch.Tensor]:
+        """bf16 / transposed operand copies of the GEMM weights, refreshed when a parameter changed."""
+        dev = self._require_cuda()
+        if self._wcache is None:
+            self._wcache = torch.zeros(self._engine.wcache_bytes, dtype=torch.uint8, device=dev)
+            self._wcache_version = -1
+        if self._engine.act == _lib.MAE_BF16:
+            v = self._params_version()
+            if v != self._wcache_version:
+                check(lib.mae_engine_refresh_weights(self._engine.handle, _ptr(self._arena), _ptr(self._wcache), _stream(dev)))
+                self._wcache_version = v
+        return self._wcache
+
+    def _ws(self, batch: int, num_keep: int) -> torch.Tensor:
+        need = self._engine.workspace_bytes(batch, num_keep)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != self._arena.device:
+            self._workspace = None  # release before growing
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self._arena.device)
+        return self._workspace
+
+    def _scratch_f32(self) -> torch.Tensor:
+        if self._scratch is None or self._scratch.device != self._arena.device:
+            self._scratch = torch.zeros(8192, dtype=torch.float32, device=self._arena.device)
+        return self._scratch
+
+    def num_keep(self, mask_ratio: Optional[float] = None) -> int:
+        r = self.mask_ratio if mask_ratio is None else mask_ratio
+        return max(1, int(self.sequence_length * (1 - r)))  # lightly random_token_mask
+
+    # ------------------------------------------------------------------ reference API
+    def random_token_mask(self, batch_size: int, noise: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """lightly utils.random_token_mask (called at src/models/mae.py:79-83): idx_keep, idx_mask int64."""
+        dev = self._require_cuda()
+        L, k = self.sequence_length, self.num_keep()
+        if noise is None:
+            noise = torch.rand(batch_size, L, device=dev)
+        noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        if noise.shape != (batch_size, L):
+            raise ValueError(f"noise must be ({batch_size}, {L}), got {tuple(noise.shape)}")
+        keep = torch.empty(batch_size, k, dtype=torch.int64, device=dev)
+        mask = torch.empty(batch_size, L - k, dtype=torch.int64, device=dev)
+        check(lib.mae_mask_from_noise(_ptr(noise), batch_size, L, k, _ptr(keep), _ptr(mask), _stream(dev)))
+        return keep, mask
+
+    def _check_images(self, images: torch.Tensor) -> torch.Tensor:
+        if images.dim() != 4 or images.shape[1] != self.in_chans or images.shape[2] != self.image_size or images.shape[3] != self.image_size:
+            raise ValueError(f"Input size {tuple(images.shape)} doesn't match model "
+                             f"(B, {self.in_chans}, {self.image_size}, {self.image_size})")  # timm PatchEmbed assert
+        return images.to(dtype=torch.float32).contiguous()
+
+    def _check_idx(self, idx: torch.Tensor, batch: int, what: str) -> torch.Tensor:
+        if idx.dim() != 2 or idx.shape[0] != batch:
+            raise ValueError(f"{what} must be (batch, n), got {tuple(idx.shape)}")
+        idx = idx.to(dtype=torch.int64).contiguous()
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= self.sequence_length):
+            raise IndexError(f"{what} out of range [0, {self.sequence_length})")
+        return idx
+
+    @torch.no_grad()
+    def forward_encoder(self, images: torch.Tensor, idx_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """src/models/mae.py:54-55.  Not differentiable on its own (use forward())."""
+        dev = self._require_cuda()
+        images = self._check_images(images)
+        B = images.shape[0]
+        if idx_keep is None:
+            idx_keep = torch.arange(self.sequence_length, device=dev).repeat(B, 1)
+        idx_keep = self._check_idx(idx_keep.to(dev), B, "idx_keep")
+        k = idx_keep.shape[1]
+        ws = self._ws(B, k)
+        self._ws_generation += 1
+        out = torch.empty(B, k, self._dims["embed_dim"], dtype=torch.float32, device=dev)
+        check(lib.mae_engine_forward_encoder(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images),
+                                            _ptr(idx_keep), B, k, _ptr(ws), ws.numel(), _ptr(out), _stream(dev)))
+        return out
+
+    @torch.no_grad()
+    def forward_decoder(self, x_encoded: torch.Tensor, idx_keep: torch.Tensor, idx_mask: torch.Tensor) -> torch.Tensor:
+        """src/models/mae.py:57-75.  Not differentiable on its own (use forward())."""
+        dev = self._require_cuda()
+        B = x_encoded.shape[0]
+        idx_keep = self._check_idx(idx_keep.to(dev), B, "idx_keep")
+        idx_mask = self._check_idx(idx_mask.to(dev), B, "idx_mask")
+        k, m = idx_keep.shape[1], idx_mask.shape[1]
+        if tuple(x_encoded.shape) != (B, k, self._dims["embed_dim"]):
+            raise ValueError(f"x_encoded must be ({B}, {k}, {self._dims['embed_dim']}), got {tuple(x_encoded.shape)}")
+        if k + m != self.sequence_length:
+            raise ValueError("idx_keep and idx_mask must partition the sequence")
+        x_encoded = x_encoded.to(device=dev, dtype=torch.float32).contiguous()
+        ws = self._ws(B, k)
+        self._ws_generation += 1
+        out = torch.empty(B, m, self.patch_dim, dtype=torch.float32, device=dev)
+        check(lib.mae_engine_forward_decoder(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(x_encoded),
+                                            _ptr(idx_keep), _ptr(idx_mask), B, k, m, _ptr(ws), ws.numel(), _ptr(out), _stream(dev)))
+        return out
+
+    def patchify_gather(self, images: torch.Tensor, idx_mask: torch.Tensor) -> torch.Tensor:
+        """utils.patchify + get_at_index(clamp(idx_mask - 1, 0)) (src/models/mae.py:90-92)."""
+        dev = self._require_cuda()
+        B, m = idx_mask.shape
+        target = torch.empty(B, m, self.patch_dim, dtype=torch.float32, device=dev)
+        check(lib.mae_patchify_gather(_ptr(images, torch.float32), _ptr(idx_mask, torch.int64), B, self.in_chans, self.image_size,
+                                     self.patch_size, m, _ptr(target), _stream(dev)))
+        return target
+
+    def _run_forward(self, images, idx_keep, idx_mask):
+        dev = self._require_cuda()
+        B, k, m = images.shape[0], idx_keep.shape[1], idx_mask.shape[1]
+        ws = self._ws(B, k)
+        self._ws_generation += 1
+        h, w = self._engine.handle, self._weights()
+        x_pred = torch.empty(B, m, self.patch_dim, dtype=torch.float32, device=dev)
+        check(lib.mae_engine_forward_encoder(h, _ptr(self._arena), _ptr(w), _ptr(images), _ptr(idx_keep), B, k, _ptr(ws), ws.numel(),
+                                            None, _stream(dev)))
+        check(lib.mae_engine_forward_decoder(h, _ptr(self._arena), _ptr(w), None, _ptr(idx_keep), _ptr(idx_mask), B, k, m, _ptr(ws),
+                                            ws.numel(), _ptr(x_pred), _stream(dev)))
+        return x_pred, self.patchify_gather(images, idx_mask)
+
+    def _run_backward(self, d_pred: torch.Tensor, B: int, k: int, m: int) -> List[torch.Tensor]:
+        dev = self._require_cuda()
+        ws = self._ws(B, k)
+        g = torch.zeros(self._engine.trainable_elems, dtype=torch.float32, device=dev)
+        check(lib.mae_engine_backward(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(d_pred), None, B, k, m,
+                                     _ptr(ws), ws.numel(), _ptr(g), _stream(dev)))
+        out = []
+        for (name, off, numel, shape, flags) in self._engine.table:
+            if flags & _lib.PARAM_TRAINABLE:
+                out.append(g[off:off + numel].view(shape))
+        return out
+
+    def forward(self, images: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        """src/models/mae.py:77-94: returns (x_pred, target), both (B, num_masked, p*p*C) fp32."""
+        self._require_cuda()
+        images = self._check_images(images)
+        idx_keep, idx_mask = self.random_token_mask(images.shape[0], noise)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._trainable):
+            return _MAEFunction.apply(self, images, idx_keep, idx_mask, *self._trainable)
+        return self._run_forward(images, idx_keep, idx_mask)
+
+    # ------------------------------------------------------------------ fused step pieces (used by training.py)
+    def loss_and_grads(self, images: torch.Tensor, noise: torch.Tensor, grad_scale: float = 1.0,
+                       return_indices: bool = False):
+        """zero_grad + mask + forward + MSE + backward in one native call (src/training/mae.py:45-50 + loss.backward()).
+        Gradients land in ``flat_grads``; returns the device scalar loss (no host sync)."""
+        dev = self._require_cuda()
+        images = self._check_images(images)
+        B, L, k = images.shape[0], self.sequence_length, self.num_keep()
+        if noise.shape != (B, L) or noise.dtype != torch.float32 or not noise.is_contiguous():
+            raise ValueError(f"noise must be a contiguous fp32 ({B}, {L}) tensor")
+        ws = self._ws(B, k)
+        self._ws_generation += 1
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        keep = mask = None
+        if return_indices:
+            keep = torch.empty(B, k, dtype=torch.int64, device=dev)
+            mask = torch.empty(B, L - k, dtype=torch.int64, device=dev)
+        check(lib.mae_engine_loss_and_grads(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images), _ptr(noise),
+                                           B, k, float(grad_scale), _ptr(ws), ws.numel(), _ptr(self.flat_grads), _ptr(loss),
+                                           _ptr(keep), _ptr(mask), _stream(dev)))
+        return (loss, keep, mask) if return_indices else loss
+
+    def named_flat_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """state_dict-named views of a flat trainable-range buffer (grads, exp_avg, ...)."""
+        return {name: flat[off:off + numel].view(shape) for (name, off, numel, shape, flags) in self._engine.table
+                if flags & _lib.PARAM_TRAINABLE}
+
+
+def _sincos_2d(embed_dim: int, grid: int) -> torch.Tensor:
+    """2-D sin-cos position table with a zero class-token row, laid out as MAE-official / lightly build it
+    (first half of the channels from the w coordinate)."""
+    if embed_dim % 4:
+        raise ValueError("sin-cos position embedding needs embed_dim % 4 == 0")
+    gw, gh = torch.meshgrid(torch.arange(grid, dtype=torch.float32), torch.arange(grid, dtype=torch.float32), indexing="xy")
+
+    def one_d(dim: int, pos: torch.Tensor) -> torch.Tensor:
+        omega = 1.0 / (10000.0 ** (torch.arange(dim // 2, dtype=torch.float32) / (dim / 2.0)))
+        out = pos.reshape(-1)[:, None] * omega[None, :]
+        return torch.cat([out.sin(), out.cos()], dim=1)
+
+    emb = torch.cat([one_d(embed_dim // 2, gw), one_d(embed_dim // 2, gh)], dim=1)
+    return torch.cat([torch.zeros(1, embed_dim), emb], dim=0).unsqueeze(0)

@@ -1,0 +1,208 @@
+"""Kernel-level parity (-m gpu): every exported HIP kernel, called through the C ABI, against a plain fp32 torch
+restatement of the same op on the same seeded inputs.  Integer outputs bit-exact; fp32 kernels to ~1e-5; bf16 kernels
+against an fp32 reference fed the same bf16-rounded operands, tolerance stated per test."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import BF16, F32, TDT, check, lib, max_err, rel_err, stream, _ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def G(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ----------------------------------------------------------------------------------------------- mask
+@pytest.mark.parametrize("B,L,k", [(1, 145, 36), (7, 145, 36), (64, 145, 72), (3, 17, 4), (2, 145, 145), (5, 257, 1), (2000, 145, 36)])
+def test_mask_from_noise_bit_exact(dev, B, L, k):
+    noise = torch.rand(B, L, generator=G(73 + B))
+    ref = noise.clone()
+    ref[:, 0] = -1
+    order = torch.argsort(ref, dim=1, stable=True)
+    keep = torch.empty(B, k, dtype=torch.int64, device=dev)
+    mask = torch.empty(B, max(L - k, 1), dtype=torch.int64, device=dev)
+    check(lib.mae_mask_from_noise(_ptr(noise.to(dev)), B, L, k, _ptr(keep), _ptr(mask), stream(dev)))
+    assert torch.equal(keep.cpu(), order[:, :k])
+    if L > k:
+        assert torch.equal(mask.cpu()[:, : L - k], order[:, k:])
+    assert bool((keep[:, 0] == 0).all())
+
+
+def test_mask_ties_broken_by_index(dev):
+    # duplicated noise values (incl. a duplicate of column 0's original value, which is overwritten by -1)
+    noise = torch.rand(4, 145, generator=G(5))
+    noise[0, 10] = noise[0, 99]
+    noise[1, 3:9] = 0.25
+    noise[2, :] = 0.5
+    noise[3, 144] = noise[3, 0]
+    ref = noise.clone(); ref[:, 0] = -1
+    order = torch.argsort(ref, dim=1, stable=True)
+    assert torch.equal(order, torch.argsort(ref, dim=1))  # CPU torch.argsort is stable here (what lightly calls)
+    keep = torch.empty(4, 36, dtype=torch.int64, device=dev)
+    mask = torch.empty(4, 109, dtype=torch.int64, device=dev)
+    check(lib.mae_mask_from_noise(_ptr(noise.to(dev)), 4, 145, 36, _ptr(keep), _ptr(mask), stream(dev)))
+    assert torch.equal(torch.cat([keep, mask], 1).cpu(), order)
+    assert keep[2].tolist() == list(range(36))
+
+
+# ----------------------------------------------------------------------------------------------- patchify / mse
+@pytest.mark.parametrize("B,C,img,p,m", [(3, 3, 96, 8, 109), (2, 3, 32, 8, 12), (2, 1, 28, 7, 5), (2, 3, 224, 14, 100)])
+def test_patchify_gather(dev, B, C, img, p, m):
+    g = G(1)
+    images = torch.rand(B, C, img, img, generator=g) * 2 - 1
+    n = (img // p) ** 2
+    idx = torch.stack([torch.randperm(n + 1, generator=g)[:m] for _ in range(B)])
+    patches = images.reshape(B, C, img // p, p, img // p, p)
+    patches = torch.einsum("nchpwq->nhwpqc", patches).reshape(B, n, p * p * C)
+    ref = torch.gather(patches, 1, (idx - 1).clamp(min=0).unsqueeze(-1).expand(-1, -1, p * p * C))
+    out = torch.empty(B, m, p * p * C, device=dev)
+    check(lib.mae_patchify_gather(_ptr(images.to(dev)), _ptr(idx.to(dev)), B, C, img, p, m, _ptr(out), stream(dev)))
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("n", [4, 192 * 109 * 3, 4096 * 1024 + 8])
+def test_mse_loss(dev, n):
+    g = G(2)
+    a, b = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    loss = torch.zeros(1, device=dev); dp = torch.empty(n, device=dev); scratch = torch.zeros(8192, device=dev)
+    check(lib.mae_mse_loss(_ptr(a.to(dev)), _ptr(b.to(dev)), n, 0.5, _ptr(loss), _ptr(dp), _ptr(scratch), stream(dev)))
+    ref = F.mse_loss(a.double(), b.double())
+    assert abs(loss.item() - ref.item()) <= 2e-6 * ref.item()
+    assert rel_err(dp, 0.5 * 2 * (a - b) / n) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------- layernorm
+@pytest.mark.parametrize("rows,dim", [(5, 144), (72, 192), (1000, 384), (33, 768), (9, 1024), (4, 8)])
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_layernorm_fwd_bwd(dev, rows, dim, dt):
+    g = G(rows + dim)
+    x = torch.randn(rows, dim, generator=g) * 2 + 0.3
+    gamma, beta = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    dy = torch.randn(rows, dim, generator=g)
+    res = torch.randn(rows, dim, generator=g)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    yref = F.layer_norm(xr, (dim,), gr, br, 1e-6)
+    dy_used = dy.to(TDT[dt]).float()
+    yref.backward(dy_used)
+    y = torch.empty(rows, dim, dtype=TDT[dt], device=dev)
+    mean = torch.empty(rows, device=dev); rstd = torch.empty(rows, device=dev)
+    check(lib.mae_layernorm_fwd(_ptr(x.to(dev)), None, _ptr(gamma.to(dev)), _ptr(beta.to(dev)), 1e-6, rows, dim, dt, _ptr(y),
+                                _ptr(mean), _ptr(rstd), stream(dev)))
+    tol = 1e-5 if dt == F32 else 6e-3
+    assert rel_err(y.float(), yref) < tol
+    assert rel_err(mean, x.mean(1)) < 1e-5 and rel_err(rstd, (x.var(1, unbiased=False) + 1e-6).rsqrt()) < 1e-5
+    dx = res.to(dev).clone(); dxc = torch.empty(rows, dim, dtype=TDT[dt], device=dev)
+    dg = torch.empty(dim, device=dev); db = torch.empty(dim, device=dev)
+    partial = torch.zeros(2 * 1024 * dim, device=dev)
+    check(lib.mae_layernorm_bwd(_ptr(dy.to(dev).to(TDT[dt])), dt, _ptr(x.to(dev)), None, _ptr(gamma.to(dev)), _ptr(mean), _ptr(rstd),
+                                rows, dim, 1, _ptr(dx), _ptr(dxc), _ptr(dg), _ptr(db), _ptr(partial), stream(dev)))
+    assert rel_err(dx, res + xr.grad) < 2e-5
+    assert rel_err(dxc.float(), res + xr.grad) < tol
+    assert rel_err(dg, gr.grad) < 2e-5 and rel_err(db, br.grad) < 2e-5
+
+
+def test_layernorm_row_map(dev):
+    g = G(9)
+    rows_src, dim, n = 50, 192, 17
+    x = torch.randn(rows_src, dim, generator=g)
+    gamma, beta = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    rmap = torch.randperm(rows_src, generator=g)[:n].to(torch.int32)
+    y = torch.empty(n, dim, device=dev); mean = torch.empty(n, device=dev); rstd = torch.empty(n, device=dev)
+    check(lib.mae_layernorm_fwd(_ptr(x.to(dev)), _ptr(rmap.to(dev)), _ptr(gamma.to(dev)), _ptr(beta.to(dev)), 1e-6, n, dim, F32,
+                                _ptr(y), _ptr(mean), _ptr(rstd), stream(dev)))
+    ref = F.layer_norm(x[rmap.long()], (dim,), gamma, beta, 1e-6)
+    assert rel_err(y, ref) < 1e-5
+    dy = torch.randn(n, dim, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.layer_norm(xr[rmap.long()], (dim,), gamma, beta, 1e-6).backward(dy)
+    dx = torch.zeros(rows_src, dim, device=dev); dg = torch.empty(dim, device=dev); db = torch.empty(dim, device=dev)
+    partial = torch.zeros(2 * 1024 * dim, device=dev)
+    check(lib.mae_layernorm_bwd(_ptr(dy.to(dev)), F32, _ptr(x.to(dev)), _ptr(rmap.to(dev)), _ptr(gamma.to(dev)), _ptr(mean), _ptr(rstd),
+                                n, dim, 0, _ptr(dx), None, _ptr(dg), _ptr(db), _ptr(partial), stream(dev)))
+    assert rel_err(dx, xr.grad) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------- linear
+def _gelu_grad(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+LIN_SHAPES = [(70, 144, 192), (72, 432, 144), (300, 576, 144), (145, 192, 768), (513, 384, 384), (1000, 1152, 384),
+              (257, 1536, 384), (130, 384, 1536), (36, 192, 384), (218, 192, 192), (64, 16, 32), (31, 20, 24)]
+
+
+@pytest.mark.parametrize("M,N,K", LIN_SHAPES)
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("epi", ["none", "gelu", "resid", "dgelu", "none_f32out"])
+def test_linear_fwd(dev, M, N, K, dt, epi):
+    if dt == F32 and epi == "none_f32out":
+        pytest.skip("same as none")
+    g = G(M * 7 + N)
+    A = (torch.randn(M, K, generator=g)).to(TDT[dt]); W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(TDT[dt])
+    bias = torch.randn(N, generator=g)
+    acc = A.double() @ W.double().t()
+    odt = F32 if (epi in ("resid", "none_f32out") or dt == F32) else BF16
+    out = torch.full((M, N), float("nan"), dtype=TDT[odt], device=dev)
+    out2 = torch.full((M, N), float("nan"), dtype=TDT[odt], device=dev)
+    aux = None
+    mode = {"none": 0, "none_f32out": 0, "gelu": 1, "resid": 2, "dgelu": 3}[epi]
+    if epi == "resid":
+        aux = torch.randn(M, N, generator=g)
+        ref = aux.double() + acc + bias.double()
+    elif epi == "dgelu":
+        aux = torch.randn(M, N, generator=g).to(TDT[odt])
+        ref = (acc + bias.double()) * _gelu_grad(aux.double())
+    else:
+        ref = acc + bias.double()
+    check(lib.mae_linear_fwd(_ptr(A.to(dev)), _ptr(W.to(dev)), _ptr(bias.to(dev)), M, N, K, dt, mode, odt, _ptr(out),
+                             _ptr(out2) if epi == "gelu" else None, _ptr(aux.to(dev)) if aux is not None else None, stream(dev)))
+    tol = 2e-5 if odt == F32 and dt == F32 else (1e-5 if odt == F32 else 5e-3)
+    assert rel_err(out.float(), ref) < tol
+    if epi == "gelu":
+        assert rel_err(out2.float(), F.gelu(out.float().cpu().double())) < (1e-5 if odt == F32 else 5e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 144, 192), (5000, 432, 144), (4100, 192, 768), (9000, 384, 384), (300, 16, 32), (8200, 1536, 384), (6000, 384, 1536)])
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_linear_wgrad(dev, M, N, K, dt):
+    g = G(M + N + K)
+    dY = (torch.randn(M, N, generator=g)).to(TDT[dt]); A = (torch.randn(M, K, generator=g)).to(TDT[dt])
+    ref = dY.double().t() @ A.double()
+    dW = torch.full((N, K), float("nan"), device=dev); db = torch.full((N,), float("nan"), device=dev)
+    scratch = torch.zeros(lib.mae_linear_wgrad_scratch_bytes(M, N, K), dtype=torch.uint8, device=dev)
+    check(lib.mae_linear_wgrad(_ptr(dY.to(dev)), _ptr(A.to(dev)), M, N, K, dt, _ptr(dW), _ptr(db), _ptr(scratch), stream(dev)))
+    assert rel_err(dW, ref) < 2e-5
+    assert rel_err(db, dY.double().sum(0)) < 2e-5
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, B, T, H, hd):
+    q, k, v = qkv.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    s = (q @ k.transpose(-2, -1)) * hd ** -0.5
+    p = s.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B, T, H * hd), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(3, 36, 6, 24), (2, 145, 6, 32), (5, 36, 6, 64), (2, 145, 8, 64), (1, 17, 2, 24), (2, 72, 6, 64), (1, 300, 2, 32), (4, 1, 2, 32)])
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_attention_fwd_bwd(dev, B, T, H, hd, dt):
+    g = G(T * 3 + hd)
+    qkv = (torch.randn(B, T, 3 * H * hd, generator=g)).to(TDT[dt])
+    do = torch.randn(B, T, H * hd, generator=g).to(TDT[dt])
+    qr = qkv.double().requires_grad_(True)
+    oref, lref = _attn_ref(qr, B, T, H, hd)
+    oref.backward(do.double())
+    out = torch.full((B, T, H * hd), float("nan"), dtype=TDT[dt], device=dev)
+    lse = torch.empty(B, H, T, device=dev)
+    check(lib.mae_attention_fwd(_ptr(qkv.to(dev)), B, T, H, hd, dt, _ptr(out), _ptr(lse), stream(dev)))
+    tol = 2e-5 if dt == F32 else 8e-3
+    assert rel_err(out.float(), oref) < tol
+    assert max_err(lse, lref) < (1e-4 if dt == F32 else 2e-2)
+    dqkv = torch.full((B, T, 3 * H * hd), float("nan"), dtype=TDT[dt], device=dev)
+    check(lib.mae_attention_bwd(_ptr(qkv.to(dev)), _ptr(out), _ptr(do.to(dev)), _ptr(lse), B, T, H, hd, dt, _ptr(dqkv), stream(dev)))
+    assert rel_err(dqkv.float(), qr.grad) < (5e-5 if dt == F32 else 2e-2)
