@@ -1,11 +1,323 @@
-// bf16 MFMA attention kernels for gfx950 (placeholder: falls back to the any-length kernel).
+// bf16 MFMA attention for gfx950: the short sequences of MAE (36 visible tokens in the encoder, 145 in the decoder).
+//
+// One workgroup per (image, head).  Q, K, V (and dO in backward) of the head are staged once into LDS as row-major
+// [token][hd] images with a 32-byte row pad; one image serves both access kinds with no bank conflicts:
+//   * row fragments   (operand indexed by token, contraction over hd)     -> ds_read_b128
+//   * transposed frags (operand indexed by hd,   contraction over tokens)  -> 2 x ds_read_b64_tr_b16
+// Products are formed transposed (S^T = K Q^T, "key/query on the lane") so that the accumulator of the first
+// product IS the B operand of the second (P^T for O^T = V^T P^T, dS^T for dQ^T = K^T dS^T, ...): the 32-token
+// contraction chunk uses the permuted index kk(h,g,q) = 16h + 4g + q on both operands, so no lane movement and
+// no LDS round trip for P.  Softmax is online over 32-key chunks (wave shuffles across the 4 lane groups).
+//
+// Reference behaviour: F.scaled_dot_product_attention inside timm Attention.forward (no mask, no dropout).
 #include "gemm_mfma.h"
 
 namespace mae {
 
-int mfma_attention_fwd(const bf16*, int, int, int, int, bf16*, float*, hipStream_t) { return MFMA_UNSUPPORTED; }
-int mfma_attention_bwd(const bf16*, const bf16*, const bf16*, const float*, int, int, int, int, bf16*, hipStream_t) {
-  return MFMA_UNSUPPORTED;
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+
+template <int HD>
+struct AT {
+  static constexpr int RS = HD * 2 + 32;  // LDS row stride in bytes
+  static constexpr int NKS = HD / 32;     // 32-deep MFMA steps across the head dimension
+  static constexpr int NDT = HD / 16;     // 16-wide output tiles across the head dimension
+  static constexpr int CPR = HD / 8;      // 16-byte chunks per row
+};
+
+// stage rows [0,T) of a (T, HD) matrix with global row stride gs (elements) into an LDS image, zero rows [T,Tp)
+template <int HD>
+__device__ __forceinline__ void stage_image(char* s, const bf16* g, int64_t gs, int T, int Tp) {
+  for (int c = threadIdx.x; c < Tp * AT<HD>::CPR; c += blockDim.x) {
+    const int row = c / AT<HD>::CPR, cc = c - row * AT<HD>::CPR;
+    uint4 v = uint4{0, 0, 0, 0};
+    if (row < T) v = *reinterpret_cast<const uint4*>(g + row * gs + cc * 8);
+    *reinterpret_cast<uint4*>(s + row * AT<HD>::RS + cc * 16) = v;
+  }
+}
+
+// operand indexed by token row (row0 + lane&15), elements hd = ks*32 + 8*(lane>>4) .. +7
+template <int HD>
+__device__ __forceinline__ bf16x8 rowfrag(const char* s, int row0, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(s + (row0 + (lane & 15)) * AT<HD>::RS + (ks * 32 + 8 * (lane >> 4)) * 2);
+}
+
+// operand indexed by hd column (c0 + lane&15), elements = tokens j0 + 16h + 4*(lane>>4) + q, (h,q) = element>>2, &3
+template <int HD>
+__device__ __forceinline__ bf16x8 trfrag(const char* s, int j0, int c0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const char* a = s + (j0 + 4 * g + q) * AT<HD>::RS + (c0 + 4 * p) * 2;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a + 16 * AT<HD>::RS));
+  return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups that share lane&15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+}  // namespace
+
+template <int HD>
+__global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
+                                                            bf16* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sK = sQ + Tp * AT<HD>::RS;
+  char* sV = sK + Tp * AT<HD>::RS;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int64_t gs = 3ll * H * HD;
+  const bf16* base = qkv + (int64_t)b * T * gs + h * HD;
+  stage_image<HD>(sQ, base, gs, T, Tp);
+  stage_image<HD>(sK, base + (int64_t)H * HD, gs, T, Tp);
+  stage_image<HD>(sV, base + 2ll * H * HD, gs, T, Tp);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  const float sl2 = scale * kLog2e;
+  const int nq = (T + 15) >> 4, nchunks = Tp >> 5;
+  for (int qt = wave; qt < nq; qt += nwaves) {
+    bf16x8 qf[AT<HD>::NKS];
+#pragma unroll
+    for (int ks = 0; ks < AT<HD>::NKS; ++ks) qf[ks] = rowfrag<HD>(sQ, qt * 16, ks, lane);
+    f32x4 oacc[AT<HD>::NDT];
+#pragma unroll
+    for (int dt = 0; dt < AT<HD>::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lsum = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32, ks, lane), qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32 + 16, ks, lane), qf[ks], s1, 0, 0, 0);
+      }
+      // lane: query i, keys j = c*32 + 4g + r (s0) and c*32 + 16 + 4g + r (s1)
+      const int j0 = c * 32 + 4 * g;
+      float mc = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (j0 + r >= T) s0[r] = -INFINITY;
+        if (j0 + 16 + r >= T) s1[r] = -INFINITY;
+        mc = fmaxf(mc, fmaxf(s0[r], s1[r]));
+      }
+      mc = group_max(mc);
+      const float mn = fmaxf(m, mc);  // finite from chunk 0 on (key 0 is always valid)
+      const float alpha = exp2f((m - mn) * sl2);
+      float ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = exp2f((s0[r] - mn) * sl2);
+        s1[r] = exp2f((s1[r] - mn) * sl2);
+        ps += s0[r] + s1[r];
+      }
+      lsum = lsum * alpha + ps;
+      const bf16x8 pf = pack8(s0, s1);
+#pragma unroll
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt) {
+        oacc[dt] *= alpha;
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sV, c * 32, dt * 16, lane), pf, oacc[dt], 0, 0, 0);
+      }
+      m = mn;
+    }
+    lsum = group_sum(lsum);
+    const float inv = 1.0f / lsum;
+    const int tq = qt * 16 + i;
+    if (tq < T) {
+      bf16* po = out + ((int64_t)b * T + tq) * H * HD + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt) store4(po + dt * 16, oacc[dt] * inv);
+      if (g == 0) lse[((int64_t)b * H + h) * T + tq] = m * scale + __logf(lsum);
+    }
+  }
+}
+
+template <int HD>
+__global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                            const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
+                                                            int Tp, int H, float scale, bf16* __restrict__ d_qkv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sK = sQ + Tp * AT<HD>::RS;
+  char* sV = sK + Tp * AT<HD>::RS;
+  char* sdO = sV + Tp * AT<HD>::RS;
+  float* sLse = reinterpret_cast<float*>(sdO + Tp * AT<HD>::RS);  // pre-multiplied by log2(e); 1e30 on padded rows
+  float* sD = sLse + Tp;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int64_t gs = 3ll * H * HD, os = (int64_t)H * HD;
+  const bf16* base = qkv + (int64_t)b * T * gs + h * HD;
+  const bf16* obase = out + (int64_t)b * T * os + h * HD;
+  const bf16* dobase = d_out + (int64_t)b * T * os + h * HD;
+  bf16* dbase = d_qkv + (int64_t)b * T * gs + h * HD;
+  stage_image<HD>(sQ, base, gs, T, Tp);
+  stage_image<HD>(sK, base + os, gs, T, Tp);
+  stage_image<HD>(sV, base + 2 * os, gs, T, Tp);
+  stage_image<HD>(sdO, dobase, os, T, Tp);
+  for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+    float D = 0.f, l = 1e30f;
+    if (t < T) {
+#pragma unroll
+      for (int cc = 0; cc < AT<HD>::CPR; ++cc) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dobase + t * os + cc * 8);
+        const bf16x8 o = *reinterpret_cast<const bf16x8*>(obase + t * os + cc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) D = fmaf((float)a[e], (float)o[e], D);
+      }
+      l = lse[((int64_t)b * H + h) * T + t] * kLog2e;
+    }
+    sLse[t] = l;
+    sD[t] = D;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int g = lane >> 4, i = lane & 15;
+  const float sl2 = scale * kLog2e;
+  const int nt16 = (T + 15) >> 4, nchunks = Tp >> 5;
+
+  // ---- phase A: wave owns 16 queries; dQ^T[d][i] = sum_j K^T[d][j] dS^T[j][i]
+  for (int qt = wave; qt < nt16; qt += nwaves) {
+    bf16x8 qf[AT<HD>::NKS], dof[AT<HD>::NKS];
+#pragma unroll
+    for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
+      qf[ks] = rowfrag<HD>(sQ, qt * 16, ks, lane);
+      dof[ks] = rowfrag<HD>(sdO, qt * 16, ks, lane);
+    }
+    const float li = sLse[qt * 16 + i], Di = sD[qt * 16 + i];
+    f32x4 dq[AT<HD>::NDT];
+#pragma unroll
+    for (int dt = 0; dt < AT<HD>::NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunks; ++c) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+      for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32, ks, lane), qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32 + 16, ks, lane), qf[ks], s1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sV, c * 32, ks, lane), dof[ks], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sV, c * 32 + 16, ks, lane), dof[ks], p1, 0, 0, 0);
+      }
+      const int j0 = c * 32 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pa = (j0 + r < T) ? exp2f(s0[r] * sl2 - li) : 0.f;
+        const float pb = (j0 + 16 + r < T) ? exp2f(s1[r] * sl2 - li) : 0.f;
+        s0[r] = pa * (p0[r] - Di);
+        s1[r] = pb * (p1[r] - Di);
+      }
+      const bf16x8 dsf = pack8(s0, s1);
+#pragma unroll
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt)
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sK, c * 32, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
+    }
+    const int tq = qt * 16 + i;
+    if (tq < T) {
+#pragma unroll
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt) store4(dbase + tq * gs + dt * 16 + 4 * g, dq[dt] * scale);
+    }
+  }
+
+  // ---- phase B: wave owns 16 keys; dV^T[d][j] = sum_i dO^T[d][i] P[i][j], dK^T[d][j] = sum_i Q^T[d][i] dS[i][j]
+  for (int jt = wave; jt < nt16; jt += nwaves) {
+    bf16x8 kf[AT<HD>::NKS], vf[AT<HD>::NKS];
+#pragma unroll
+    for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
+      kf[ks] = rowfrag<HD>(sK, jt * 16, ks, lane);
+      vf[ks] = rowfrag<HD>(sV, jt * 16, ks, lane);
+    }
+    f32x4 dk[AT<HD>::NDT], dv[AT<HD>::NDT];
+#pragma unroll
+    for (int dt = 0; dt < AT<HD>::NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
+    for (int c = 0; c < nchunks; ++c) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
+#pragma unroll
+      for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sQ, c * 32, ks, lane), kf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sQ, c * 32 + 16, ks, lane), kf[ks], s1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sdO, c * 32, ks, lane), vf[ks], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sdO, c * 32 + 16, ks, lane), vf[ks], p1, 0, 0, 0);
+      }
+      // lane: key j = jt*16 + i; queries c*32 + 4g + r (tile 0), c*32 + 16 + 4g + r (tile 1); padded queries: lse = 1e30
+      const f32x4 l0 = load4(sLse + c * 32 + 4 * g), l1 = load4(sLse + c * 32 + 16 + 4 * g);
+      const f32x4 D0 = load4(sD + c * 32 + 4 * g), D1 = load4(sD + c * 32 + 16 + 4 * g);
+      f32x4 ds0, ds1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = exp2f(s0[r] * sl2 - l0[r]);
+        s1[r] = exp2f(s1[r] * sl2 - l1[r]);
+        ds0[r] = s0[r] * (p0[r] - D0[r]);
+        ds1[r] = s1[r] * (p1[r] - D1[r]);
+      }
+      const bf16x8 pf = pack8(s0, s1), dsf = pack8(ds0, ds1);
+#pragma unroll
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt) {
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sdO, c * 32, dt * 16, lane), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sQ, c * 32, dt * 16, lane), dsf, dk[dt], 0, 0, 0);
+      }
+    }
+    const int tj = jt * 16 + i;
+    if (tj < T) {
+#pragma unroll
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt) {
+        store4(dbase + tj * gs + os + dt * 16 + 4 * g, dk[dt] * scale);
+        store4(dbase + tj * gs + 2 * os + dt * 16 + 4 * g, dv[dt]);
+      }
+    }
+  }
+}
+
+static int attn_waves(int T) {
+  const int nt = (T + 15) / 16;
+  const int passes = (nt + 7) / 8;
+  return (nt + passes - 1) / passes;  // <= 8 waves, balanced over the 16-token tiles
+}
+
+static bool attn_supported(int T, int H, int hd) {
+  return (hd == 32 || hd == 64) && T >= 1 && T <= 1024 && ((int64_t)H * hd) % 8 == 0;
+}
+
+int mfma_attention_fwd(const bf16* qkv, int B, int T, int H, int hd, bf16* out, float* lse, hipStream_t s) {
+  if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return MFMA_UNSUPPORTED;
+  const int Tp = (int)round_up(T, 32);
+  const size_t lds = (size_t)3 * Tp * (hd * 2 + 32);
+  if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const dim3 grid((unsigned)B * H), block(64 * attn_waves(T));
+  if (hd == 64) {
+    MAE_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), grid, block, lds, s, qkv, T, Tp, H, scale, out, lse);
+  } else {
+    MAE_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<32>), grid, block, lds, s, qkv, T, Tp, H, scale, out, lse);
+  }
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int mfma_attention_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int H, int hd,
+                       bf16* d_qkv, hipStream_t s) {
+  if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)d_qkv) & 15)) return MFMA_UNSUPPORTED;
+  const int Tp = (int)round_up(T, 32);
+  const size_t lds = (size_t)4 * Tp * (hd * 2 + 32) + (size_t)2 * Tp * 4;
+  if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const dim3 grid((unsigned)B * H), block(64 * attn_waves(T));
+  if (hd == 64) {
+    MAE_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<64>), grid, block, lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv);
+  } else {
+    MAE_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<32>), grid, block, lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv);
+  }
+  MAE_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // namespace mae

@@ -1,10 +1,371 @@
-// bf16 MFMA GEMM kernels for gfx950 (placeholder: shapes not yet covered fall back to the any-shape kernel).
+// bf16 MFMA GEMMs for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate), fused epilogues.
+//
+//  gemm_nt_kernel   out[M,N] = A[M,K] * W[N,K]^T      Linear forward, and dgrad via the transposed weight copy.
+//                   Block tile 128 x (64|128) x 64, 4 waves (2x2), register-staged global->LDS with an XOR
+//                   swizzle (conflict-free ds_read_b128 fragments), double-buffered LDS, one barrier per K step.
+//                   Operands are passed to the MFMA swapped (W as A-operand) so every lane ends up with 4
+//                   consecutive output columns of one row: 8-byte (bf16) / 16-byte (fp32) epilogue stores.
+//  gemm_tn_kernel   dW[N,K] = dY[M,N]^T * X[M,K]      weight gradient: reduction over the long M dimension.
+//                   Both operand tiles are [m][*] row-major in LDS and read transposed with
+//                   ds_read_b64_tr_b16; split over M with fp32 slabs + an ordered (deterministic) reduce.
+//
+// M here is batch*tokens (72 000 .. 290 000), N/K are 192..1536: every GEMM is short-K and output-bound
+// (arithmetic intensity ~ the bf16 ridge), so the epilogue stores and the A-panel L2 reuse matter as much as the
+// MFMA schedule.  Blocks are remapped so that one XCD walks the N tiles of the same A panel (L2 reuse).
 #include "gemm_mfma.h"
 
 namespace mae {
 
-int mfma_linear_fwd(const bf16*, const bf16*, int64_t, int, int, const Epi&, hipStream_t) { return MFMA_UNSUPPORTED; }
-int64_t mfma_wgrad_scratch_bytes(int64_t, int, int) { return 0; }
-int mfma_linear_wgrad(const bf16*, const bf16*, int64_t, int, int, float*, void*, hipStream_t) { return MFMA_UNSUPPORTED; }
+// erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): one v_exp + one v_rcp; outputs are rounded to bf16 anyway.
+__device__ __forceinline__ void erf_parts(float x, float& erf_abs, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  e = __expf(-z * z);  // = exp(-x^2/2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  erf_abs = 1.0f - poly * e;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  float ea, e;
+  erf_parts(x, ea, e);
+  return 0.5f * x * (1.0f + copysignf(ea, x));
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  float ea, e;
+  erf_parts(x, ea, e);
+  return 0.5f * (1.0f + copysignf(ea, x)) + x * 0.39894228040143267794f * e;
+}
+
+struct EpiArgs {
+  const float* bias;
+  const void* aux;
+  void* out;
+  void* out2;
+};
+
+// bijective XCD remap: blocks b and b+8 share an XCD; give every XCD a contiguous run of tiles
+__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nb) {
+  const int64_t q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <int MODE, class TO, int NI>
+__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M,
+                                                         int N, int K, EpiArgs ep, int tiles_n) {
+  constexpr int BM = 128, BN = 32 * NI, BK = 64;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int NB = BN / 32;  // 16-byte chunks of the W tile per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                    // [2][A_BYTES]
+  char* sB = smem + 2 * A_BYTES;      // [2][B_BYTES]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t t = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t m0 = (t / tiles_n) * BM;
+  const int n0 = (int)(t % tiles_n) * BN;
+
+  // global -> register staging: chunk c = tid + 256 i -> (row c>>3, 16-byte chunk c&7)
+  uint4 ra[4], rb[NB];
+  const bf16* pa[4];
+  const bf16* pb[NB];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+    int64_t gm = m0 + row;
+    gm = gm < M ? gm : M - 1;  // clamp: rows past M are loaded (valid memory) but never stored
+    pa[i] = A + gm * K + kc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+    pb[i] = W + (int64_t)(n0 + row) * K + kc * 8;
+  }
+  auto g_load = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(pa[i] + k0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(pb[i] + k0);
+  };
+  auto s_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+      *reinterpret_cast<uint4*>(sA + buf * A_BYTES + row * 128 + ((kc ^ (row & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
+      *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 128 + ((kc ^ (row & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][NI];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  const int fr = lane & 15, fq = lane >> 4;
+  g_load(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    s_store(buf);
+    __syncthreads();
+    if (kt + 1 < nk) g_load((kt + 1) * BK);
+    const char* a_base = sA + buf * A_BYTES + (wm * 64 + fr) * 128;
+    const char* b_base = sB + buf * B_BYTES + (wn * (NI * 16) + fr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int sw = ((ks * 4 + fq) ^ (fr & 7)) << 4;
+      bf16x8 af[4], bfr[NI];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(b_base + ni * 16 * 128 + sw);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+  }
+
+  // epilogue: lane holds out[m][nb .. nb+3], m = tile row fr, nb = 4*fq inside each 16x16 tile
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int64_t m = m0 + wm * 64 + mi * 16 + fr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (NI * 16) + ni * 16 + fq * 4;
+      const int64_t o = m * N + n;
+      f32x4 v = acc[mi][ni];
+      if (ep.bias) v += load4(ep.bias + n);
+      if (MODE == MAE_EPI_NONE) {
+        store4(reinterpret_cast<TO*>(ep.out) + o, v);
+      } else if (MODE == MAE_EPI_GELU) {
+        f32x4 pre, act;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pre[r] = to_f(from_f<TO>(v[r]));
+          act[r] = gelu_fast(pre[r]);
+        }
+        store4(reinterpret_cast<TO*>(ep.out) + o, pre);
+        store4(reinterpret_cast<TO*>(ep.out2) + o, act);
+      } else if (MODE == MAE_EPI_RESID) {
+        v += load4(reinterpret_cast<const float*>(ep.aux) + o);
+        store4(reinterpret_cast<TO*>(ep.out) + o, v);
+      } else {
+        const f32x4 pre = load4(reinterpret_cast<const TO*>(ep.aux) + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_fast(pre[r]);
+        store4(reinterpret_cast<TO*>(ep.out) + o, v);
+      }
+    }
+  }
+}
+
+template <int MODE, class TO, int NI>
+static int launch_nt(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
+  constexpr int BN = 32 * NI;
+  const int tiles_n = N / BN;
+  const int64_t tiles = cdiv(M, 128) * tiles_n;
+  MAE_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
+  const size_t lds = 2 * (128 * 64 * 2) + 2 * (BN * 64 * 2);
+  auto kern = gemm_nt_kernel<MODE, TO, NI>;
+  MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  EpiArgs ea{e.bias, e.aux, e.out, e.out2};
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, A, W, M, N, K, ea, tiles_n);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int MODE, class TO>
+static int launch_nt_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
+  if (N % 128 == 0) return launch_nt<MODE, TO, 4>(A, W, M, N, K, e, s);
+  return launch_nt<MODE, TO, 2>(A, W, M, N, K, e, s);
+}
+
+int mfma_linear_fwd(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
+  if (K % 64 != 0 || N % 64 != 0 || M < 1) return MFMA_UNSUPPORTED;
+  if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)e.out | (uintptr_t)e.out2 | (uintptr_t)e.aux | (uintptr_t)e.bias) & 15) != 0)
+    return MFMA_UNSUPPORTED;
+  const bool f32out = e.out_dt == MAE_F32;
+  switch (e.mode) {
+    case MAE_EPI_NONE: return f32out ? launch_nt_ni<MAE_EPI_NONE, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_NONE, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_GELU: return f32out ? launch_nt_ni<MAE_EPI_GELU, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_GELU, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_RESID: return f32out ? launch_nt_ni<MAE_EPI_RESID, float>(A, W, M, N, K, e, s) : MFMA_UNSUPPORTED;
+    case MAE_EPI_DGELU: return f32out ? launch_nt_ni<MAE_EPI_DGELU, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_DGELU, bf16>(A, W, M, N, K, e, s);
+    default: return MFMA_UNSUPPORTED;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: dW[n][k] = sum_m dY[m][n] X[m][k]
+// ---------------------------------------------------------------------------------------------------
+constexpr int TN_RS = 288;  // LDS row stride in bytes for a 128-column bf16 tile row (256 B + 32 B pad): consecutive rows
+                            // shift by 8 banks, so the 8 rows one 32-lane half reads transposed are conflict-free
+
+__device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(p));
+}
+
+// NI / KI: 16-wide tiles per wave along n / k (block tile = 32*NI x 32*KI), reduction step 64 rows of m
+template <int NI, int KI>
+__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict__ dY, const bf16* __restrict__ X, int64_t M, int N,
+                                                         int K, float* __restrict__ out, int tiles_n, int tiles_k,
+                                                         int64_t m_chunk) {
+  constexpr int TNB = 32 * NI, TKB = 32 * KI, BR = 64;
+  constexpr int Y_BYTES = BR * TN_RS, X_BYTES = BR * TN_RS;
+  constexpr int YC = TNB / 8 * BR / 256;  // 16-byte chunks per thread for the dY tile (TNB/8 chunks per row)
+  constexpr int XC = TKB / 8 * BR / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sY = smem;                 // [2][Y_BYTES]
+  char* sX = smem + 2 * Y_BYTES;   // [2][X_BYTES]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int tile = blockIdx.x % (tiles_n * tiles_k);
+  const int split = blockIdx.x / (tiles_n * tiles_k);
+  const int n0 = (tile / tiles_k) * TNB, k0 = (tile % tiles_k) * TKB;
+  const int64_t mbeg = (int64_t)split * m_chunk;
+  const int64_t mend = mbeg + m_chunk < M ? mbeg + m_chunk : M;
+
+  uint4 ry[YC], rx[XC];
+  auto g_load = [&](int64_t mb) {
+#pragma unroll
+    for (int i = 0; i < YC; ++i) {
+      const int c = tid + 256 * i, row = c / (TNB / 8), cc = c % (TNB / 8);
+      const int64_t m = mb + row;
+      ry[i] = m < mend ? *reinterpret_cast<const uint4*>(dY + m * N + n0 + cc * 8) : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      const int c = tid + 256 * i, row = c / (TKB / 8), cc = c % (TKB / 8);
+      const int64_t m = mb + row;
+      rx[i] = m < mend ? *reinterpret_cast<const uint4*>(X + m * K + k0 + cc * 8) : uint4{0, 0, 0, 0};
+    }
+  };
+  auto s_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < YC; ++i) {
+      const int c = tid + 256 * i, row = c / (TNB / 8), cc = c % (TNB / 8);
+      *reinterpret_cast<uint4*>(sY + buf * Y_BYTES + row * TN_RS + cc * 16) = ry[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XC; ++i) {
+      const int c = tid + 256 * i, row = c / (TKB / 8), cc = c % (TKB / 8);
+      *reinterpret_cast<uint4*>(sX + buf * X_BYTES + row * TN_RS + cc * 16) = rx[i];
+    }
+  };
+
+  f32x4 acc[KI][NI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read address of this lane inside a 32-row k-substep: rows 16h + 4g + q, columns cb + 4p .. 4p+3
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int lane_off = (4 * g + q) * TN_RS + p * 8;
+
+  const int64_t nsteps = (mend - mbeg + BR - 1) / BR;
+  g_load(mbeg);
+  for (int64_t st = 0; st < nsteps; ++st) {
+    const int buf = (int)(st & 1);
+    s_store(buf);
+    __syncthreads();
+    if (st + 1 < nsteps) g_load(mbeg + (st + 1) * BR);
+    const char* yb = sY + buf * Y_BYTES + lane_off + (wn * NI * 16) * 2;
+    const char* xb = sX + buf * X_BYTES + lane_off + (wk * KI * 16) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 yf[NI], xf[KI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const bf16x4 lo = lds_read_tr(yb + (ks * 32) * TN_RS + ni * 32);
+        const bf16x4 hi = lds_read_tr(yb + (ks * 32 + 16) * TN_RS + ni * 32);
+        yf[ni] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int ki = 0; ki < KI; ++ki) {
+        const bf16x4 lo = lds_read_tr(xb + (ks * 32) * TN_RS + ki * 32);
+        const bf16x4 hi = lds_read_tr(xb + (ks * 32 + 16) * TN_RS + ki * 32);
+        xf[ki] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int ki = 0; ki < KI; ++ki)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ki], yf[ni], acc[ki][ni], 0, 0, 0);
+    }
+  }
+  // D[i = k][j = n]: lane holds n = tile col (lane&15), k = 4*(lane>>4) + r -> 16-byte store along k
+  float* o = out + (int64_t)split * N * K;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * NI * 16 + ni * 16 + (lane & 15);
+#pragma unroll
+    for (int ki = 0; ki < KI; ++ki) {
+      const int k = k0 + wk * KI * 16 + ki * 16 + (lane >> 4) * 4;
+      store4(o + (int64_t)n * K + k, acc[ki][ni]);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n4, float* __restrict__ out) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 acc = load4(slabs + i * 4);
+    for (int s = 1; s < S; ++s) acc += load4(slabs + ((int64_t)s * n4 + i) * 4);
+    store4(out + i * 4, acc);
+  }
+}
+
+static int wgrad_splits(int64_t M, int N, int K) {
+  const int tn = N % 128 == 0 ? 128 : 64, tk = K % 128 == 0 ? 128 : 64;
+  const int64_t tiles = (int64_t)(N / tn) * (K / tk);
+  int64_t S = std::max<int64_t>(1, 512 / tiles);
+  S = std::min<int64_t>(S, std::max<int64_t>(1, M / 512));  // at least 8 reduction steps per block
+  return (int)std::min<int64_t>(S, 64);
+}
+
+int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K) {
+  if (N % 64 != 0 || K % 64 != 0) return 0;
+  const int S = wgrad_splits(M, N, K);
+  return S > 1 ? round_up((int64_t)S * N * K * 4, 256) : 0;
+}
+
+template <int NI, int KI>
+static int launch_tn(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* out, int S, int64_t m_chunk, hipStream_t s) {
+  const int tiles_n = N / (32 * NI), tiles_k = K / (32 * KI);
+  const size_t lds = 4 * 64 * TN_RS;
+  auto kern = gemm_tn_kernel<NI, KI>;
+  MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(256), lds, s, dY, X, M, N, K, out, tiles_n, tiles_k, m_chunk);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* dW, void* slab, hipStream_t s) {
+  if (N % 64 != 0 || K % 64 != 0 || M < 1) return MFMA_UNSUPPORTED;
+  if ((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)slab) & 15) != 0) return MFMA_UNSUPPORTED;
+  const int S = wgrad_splits(M, N, K);
+  if (S > 1 && !slab) return MFMA_UNSUPPORTED;
+  const int64_t m_chunk = round_up(cdiv(M, S), 64);
+  float* out = S > 1 ? reinterpret_cast<float*>(slab) : dW;
+  const bool n128 = N % 128 == 0, k128 = K % 128 == 0;
+  int r;
+  if (n128 && k128) r = launch_tn<4, 4>(dY, X, M, N, K, out, S, m_chunk, s);
+  else if (n128) r = launch_tn<4, 2>(dY, X, M, N, K, out, S, m_chunk, s);
+  else if (k128) r = launch_tn<2, 4>(dY, X, M, N, K, out, S, m_chunk, s);
+  else r = launch_tn<2, 2>(dY, X, M, N, K, out, S, m_chunk, s);
+  if (r) return r;
+  if (S > 1) {
+    const int64_t n4 = (int64_t)N * K / 4;
+    const int grid = (int)std::min<int64_t>(cdiv(n4, 256), 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)slab, S, n4, dW);
+    MAE_LAUNCH_CHECK();
+  }
+  return 0;
+}
 
 }  // namespace mae

@@ -22,3 +22,19 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
 
 def max_err(a, b) -> float:
     return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+# Device copies made inline in a call expression must outlive the launch: a temporary freed between two `_ptr(...)`
+# arguments can be handed out again by the caching allocator for the next argument.
+_KEEP = []
+
+
+def dv(t: torch.Tensor, dtype=None) -> torch.Tensor:
+    d = t.to("cuda") if dtype is None else t.to("cuda").to(dtype)
+    _KEEP.append(d)
+    return d
+
+
+def release_device_copies() -> None:
+    torch.cuda.synchronize()
+    _KEEP.clear()
