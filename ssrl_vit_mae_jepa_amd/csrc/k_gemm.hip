@@ -161,14 +161,6 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ dY, i
   }
 }
 
-__global__ void __launch_bounds__(256) colsum_final_kernel(const float* __restrict__ partial, int nb, int N, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
-  float acc = 0.f;
-  for (int i = 0; i < nb; ++i) acc += partial[(int64_t)i * N + c];
-  out[c] = acc;
-}
-
 int64_t linear_wgrad_scratch_bytes(int64_t M, int N, int K) {
   return round_up((int64_t)COLSUM_BLOCKS * N * 4, 256) + mfma_wgrad_scratch_bytes(M, N, K);
 }
@@ -184,8 +176,7 @@ int launch_linear_wgrad(const void* dY, const void* A, int64_t M, int N, int K, 
     if (dt == MAE_BF16) hipLaunchKernelGGL((colsum_kernel<bf16>), grid, dim3(256), 0, s, (const bf16*)dY, M, N, (float*)scratch);
     else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dY, M, N, (float*)scratch);
     MAE_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, s, (const float*)scratch, G, N, db);
-    MAE_LAUNCH_CHECK();
+    MAE_TRY(launch_sum_partials((const float*)scratch, G, N, db, nullptr, N, s));
   }
   if (dt == MAE_BF16) {
     void* slab = scratch ? (char*)scratch + round_up((int64_t)COLSUM_BLOCKS * N * 4, 256) : nullptr;

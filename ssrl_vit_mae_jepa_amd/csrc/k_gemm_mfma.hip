@@ -63,40 +63,35 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
   const int64_t m0 = (t / tiles_n) * BM;
   const int n0 = (int)(t % tiles_n) * BN;
 
-  // global -> register staging: chunk c = tid + 256 i -> (row c>>3, 16-byte chunk c&7)
-  uint4 ra[4], rb[NB];
-  const bf16* pa[4];
-  const bf16* pb[NB];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-    int64_t gm = m0 + row;
-    gm = gm < M ? gm : M - 1;  // clamp: rows past M are loaded (valid memory) but never stored
-    pa[i] = A + gm * K + kc * 8;
+  // global -> register staging: chunk c = tid + 256 i -> (row c>>3, 16-byte chunk c&7).  Named scalars, not
+  // arrays: hipcc kept uint4 staging arrays in scratch memory here (a vmcnt(0) + scratch round trip per load).
+  const int srow = tid >> 3, skc = tid & 7;  // chunk i covers row srow + 32 i
+  const bf16 *pa0, *pa1, *pa2, *pa3, *pb0, *pb1, *pb2 = nullptr, *pb3 = nullptr;
+  {
+    auto arow = [&](int i) { int64_t gm = m0 + srow + 32 * i; return A + (gm < M ? gm : M - 1) * K + skc * 8; };  // clamp: rows past M are loaded, never stored
+    pa0 = arow(0); pa1 = arow(1); pa2 = arow(2); pa3 = arow(3);
+    pb0 = W + (int64_t)(n0 + srow) * K + skc * 8;
+    pb1 = pb0 + 32ll * K;
+    if (NB > 2) { pb2 = pb0 + 64ll * K; pb3 = pb0 + 96ll * K; }
   }
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-    pb[i] = W + (int64_t)(n0 + row) * K + kc * 8;
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = uint4{0, 0, 0, 0}, rb3 = uint4{0, 0, 0, 0};
+  const int soff = srow * 128 + ((skc ^ (srow & 7)) << 4);  // (srow + 32 i) & 7 == srow & 7
+#define LD16(p, k0) (*reinterpret_cast<const uint4*>((p) + (k0)))
+#define NT_G_LOAD(k0)                                                                 \
+  {                                                                                   \
+    ra0 = LD16(pa0, k0); ra1 = LD16(pa1, k0); ra2 = LD16(pa2, k0); ra3 = LD16(pa3, k0); \
+    rb0 = LD16(pb0, k0); rb1 = LD16(pb1, k0);                                         \
+    if (NB > 2) { rb2 = LD16(pb2, k0); rb3 = LD16(pb3, k0); }                         \
   }
-  auto g_load = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(pa[i] + k0);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const uint4*>(pb[i] + k0);
-  };
-  auto s_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-      *reinterpret_cast<uint4*>(sA + buf * A_BYTES + row * 128 + ((kc ^ (row & 7)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int c = tid + 256 * i, row = c >> 3, kc = c & 7;
-      *reinterpret_cast<uint4*>(sB + buf * B_BYTES + row * 128 + ((kc ^ (row & 7)) << 4)) = rb[i];
-    }
-  };
+#define ST16(base, i, v) (*reinterpret_cast<uint4*>((base) + soff + (i) * 32 * 128) = (v))
+#define NT_S_STORE(buf)                                                               \
+  {                                                                                   \
+    char* _a = sA + (buf) * A_BYTES;                                                  \
+    char* _b = sB + (buf) * B_BYTES;                                                  \
+    ST16(_a, 0, ra0); ST16(_a, 1, ra1); ST16(_a, 2, ra2); ST16(_a, 3, ra3);           \
+    ST16(_b, 0, rb0); ST16(_b, 1, rb1);                                               \
+    if (NB > 2) { ST16(_b, 2, rb2); ST16(_b, 3, rb3); }                               \
+  }
 
   f32x4 acc[4][NI];
 #pragma unroll
@@ -106,12 +101,12 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
 
   const int nk = K / BK;
   const int fr = lane & 15, fq = lane >> 4;
-  g_load(0);
+  NT_G_LOAD(0)
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    s_store(buf);
+    NT_S_STORE(buf)
     __syncthreads();
-    if (kt + 1 < nk) g_load((kt + 1) * BK);
+    if (kt + 1 < nk) NT_G_LOAD((kt + 1) * BK)
     const char* a_base = sA + buf * A_BYTES + (wm * 64 + fr) * 128;
     const char* b_base = sB + buf * B_BYTES + (wn * (NI * 16) + fr) * 128;
 #pragma unroll
@@ -231,32 +226,30 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
   const int64_t mend = mbeg + m_chunk < M ? mbeg + m_chunk : M;
 
   uint4 ry[YC], rx[XC];
-  auto g_load = [&](int64_t mb) {
-#pragma unroll
-    for (int i = 0; i < YC; ++i) {
-      const int c = tid + 256 * i, row = c / (TNB / 8), cc = c % (TNB / 8);
-      const int64_t m = mb + row;
-      ry[i] = m < mend ? *reinterpret_cast<const uint4*>(dY + m * N + n0 + cc * 8) : uint4{0, 0, 0, 0};
-    }
-#pragma unroll
-    for (int i = 0; i < XC; ++i) {
-      const int c = tid + 256 * i, row = c / (TKB / 8), cc = c % (TKB / 8);
-      const int64_t m = mb + row;
-      rx[i] = m < mend ? *reinterpret_cast<const uint4*>(X + m * K + k0 + cc * 8) : uint4{0, 0, 0, 0};
-    }
-  };
-  auto s_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < YC; ++i) {
-      const int c = tid + 256 * i, row = c / (TNB / 8), cc = c % (TNB / 8);
-      *reinterpret_cast<uint4*>(sY + buf * Y_BYTES + row * TN_RS + cc * 16) = ry[i];
-    }
-#pragma unroll
-    for (int i = 0; i < XC; ++i) {
-      const int c = tid + 256 * i, row = c / (TKB / 8), cc = c % (TKB / 8);
-      *reinterpret_cast<uint4*>(sX + buf * X_BYTES + row * TN_RS + cc * 16) = rx[i];
-    }
-  };
+#define TN_G_LOAD(mb)                                                                         \
+  {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < YC; ++i) {                                          \
+      const int c = tid + 256 * i, row = c / (TNB / 8), cc = c % (TNB / 8);                   \
+      const int64_t m = (mb) + row;                                                           \
+      ry[i] = m < mend ? *reinterpret_cast<const uint4*>(dY + m * N + n0 + cc * 8) : uint4{0, 0, 0, 0}; \
+    }                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < XC; ++i) {                                          \
+      const int c = tid + 256 * i, row = c / (TKB / 8), cc = c % (TKB / 8);                   \
+      const int64_t m = (mb) + row;                                                           \
+      rx[i] = m < mend ? *reinterpret_cast<const uint4*>(X + m * K + k0 + cc * 8) : uint4{0, 0, 0, 0}; \
+    }                                                                                         \
+  }
+#define TN_S_STORE(buf)                                                                       \
+  {                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < YC; ++i) {                                          \
+      const int c = tid + 256 * i, row = c / (TNB / 8), cc = c % (TNB / 8);                   \
+      *reinterpret_cast<uint4*>(sY + (buf) * Y_BYTES + row * TN_RS + cc * 16) = ry[i];        \
+    }                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < XC; ++i) {                                          \
+      const int c = tid + 256 * i, row = c / (TKB / 8), cc = c % (TKB / 8);                   \
+      *reinterpret_cast<uint4*>(sX + (buf) * X_BYTES + row * TN_RS + cc * 16) = rx[i];        \
+    }                                                                                         \
+  }
 
   f32x4 acc[KI][NI];
 #pragma unroll
@@ -269,12 +262,12 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
   const int lane_off = (4 * g + q) * TN_RS + p * 8;
 
   const int64_t nsteps = (mend - mbeg + BR - 1) / BR;
-  g_load(mbeg);
+  TN_G_LOAD(mbeg)
   for (int64_t st = 0; st < nsteps; ++st) {
     const int buf = (int)(st & 1);
-    s_store(buf);
+    TN_S_STORE(buf)
     __syncthreads();
-    if (st + 1 < nsteps) g_load(mbeg + (st + 1) * BR);
+    if (st + 1 < nsteps) TN_G_LOAD(mbeg + (st + 1) * BR)
     const char* yb = sY + buf * Y_BYTES + lane_off + (wn * NI * 16) * 2;
     const char* xb = sX + buf * X_BYTES + lane_off + (wk * KI * 16) * 2;
 #pragma unroll

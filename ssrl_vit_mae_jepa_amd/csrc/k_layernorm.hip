@@ -144,15 +144,6 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) layernorm_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int dim,
-                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * dim) return;
-  float acc = 0.f;
-  for (int i = 0; i < nb; ++i) acc += partial[(int64_t)i * 2 * dim + c];
-  if (c < dim) dgamma[c] = acc; else dbeta[c - dim] = acc;
-}
-
 int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_t* row_map, const float* gamma,
                          const float* mean, const float* rstd, int64_t rows, int dim, int accumulate, float* dx_io,
                          void* dx_copy, float* dgamma, float* dbeta, float* partial, hipStream_t s) {
@@ -167,9 +158,7 @@ int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_
 #undef LNB_NV
 #undef LNB
   MAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(layernorm_bwd_finalize_kernel, dim3((int)cdiv(2 * dim, 256)), dim3(256), 0, s, partial, grid, dim, dgamma, dbeta);
-  MAE_LAUNCH_CHECK();
-  return 0;
+  return launch_sum_partials(partial, grid, 2 * dim, dgamma, dbeta, dim, s);
 }
 
 }  // namespace mae

@@ -88,15 +88,30 @@ int launch_assemble_visible(float* x, const int32_t* tok, const float* cls, cons
   return 0;
 }
 
-// Column sums of selected rows, two stages, deterministic.  Stage 1: block i sums rows i, i+G, ... into
-// partial[i][D]; stage 2: one thread per column adds the G partials in order.
-__global__ void __launch_bounds__(256) colsum_finalize_kernel(const float* __restrict__ partial, int G, int D,
-                                                              float* __restrict__ out) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
+// Second stage of every two-stage column reduction: 32 columns per block, 8 row lanes per column, fixed order.
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ partial, int G, int C,
+                                                           float* __restrict__ out0, float* __restrict__ out1, int split) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float acc = 0.f;
-  for (int i = 0; i < G; ++i) acc += partial[(int64_t)i * D + d];
-  out[d] = acc;
+  if (c < C)
+    for (int i = rl; i < G; i += 8) acc += partial[(int64_t)i * C + c];
+  red[rl][cl] = acc;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float v = red[0][cl];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) v += red[j][cl];
+    if (c < split) out0[c] = v; else out1[c - split] = v;
+  }
+}
+
+int launch_sum_partials(const float* partial, int G, int C, float* out0, float* out1, int split, hipStream_t s) {
+  MAE_REQUIRE(partial && out0 && G > 0 && C > 0 && (split >= C || out1), "sum_partials: bad arguments");
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, s, partial, G, C, out0, out1, split);
+  MAE_LAUNCH_CHECK();
+  return 0;
 }
 
 // Row-walk helper shared by the two "split" kernels: thread (ro, c4) owns 4 columns of row offset ro; a block
@@ -141,9 +156,7 @@ int launch_visible_grad_split(const float* dx, const int32_t* tok, int64_t rows,
   else
     hipLaunchKernelGGL((visible_grad_split_kernel<float>), dim3(G), dim3(256), lds, s, dx, tok, rows, D, (float*)dtok, partial);
   MAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((int)cdiv(D, 256)), dim3(256), 0, s, partial, G, D, dcls);
-  MAE_LAUNCH_CHECK();
-  return 0;
+  return launch_sum_partials(partial, G, D, dcls, nullptr, D, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -224,9 +237,7 @@ int launch_decoder_assemble_bwd(const float* dx, const int32_t* inv, const int32
   else
     hipLaunchKernelGGL((decoder_assemble_bwd_kernel<float>), dim3(G), dim3(256), lds, s, dx, inv, rows, k, L, Dd, (float*)d_xdec, partial);
   MAE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((int)cdiv(Dd, 256)), dim3(256), 0, s, partial, G, Dd, d_mask_token);
-  MAE_LAUNCH_CHECK();
-  return 0;
+  return launch_sum_partials(partial, G, Dd, d_mask_token, nullptr, Dd, s);
 }
 
 // ---------------------------------------------------------------------------------------------------
