@@ -13,7 +13,8 @@ int mfma_linear_fwd(const bf16* A, const bf16* W, int64_t M, int N, int K, const
 
 // dW[N,K] = dY[M,N]^T * A[M,K] (fp32, written)
 int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K);
-int mfma_linear_wgrad(const bf16* dY, const bf16* A, int64_t M, int N, int K, float* dW, void* slab, hipStream_t s);
+// also db[N] = column sums of dY when db != null
+int mfma_linear_wgrad(const bf16* dY, const bf16* A, int64_t M, int N, int K, float* dW, float* db, void* slab, hipStream_t s);
 
 // attention (k_attention_mfma.hip)
 int mfma_attention_fwd(const bf16* qkv, int B, int T, int H, int hd, bf16* out, float* lse, hipStream_t s);

@@ -170,6 +170,11 @@ int launch_linear_wgrad(const void* dY, const void* A, int64_t M, int N, int K, 
   MAE_REQUIRE(dY && A && dW && M > 0 && N > 0 && K > 0, "linear_wgrad: bad arguments");
   MAE_REQUIRE(dt == MAE_F32 || dt == MAE_BF16, "linear_wgrad: bad dtype");
   MAE_REQUIRE(!db || (scratch && N % 4 == 0), "linear_wgrad: bias gradient needs scratch and N %% 4 == 0");
+  if (dt == MAE_BF16) {
+    void* slab = scratch ? (char*)scratch + round_up((int64_t)COLSUM_BLOCKS * N * 4, 256) : nullptr;
+    const int r = mfma_linear_wgrad((const bf16*)dY, (const bf16*)A, M, N, K, dW, db, slab, s);
+    if (r != MFMA_UNSUPPORTED) return r;
+  }
   if (db) {
     const int G = (int)std::min<int64_t>(cdiv(M, 4), COLSUM_BLOCKS);
     dim3 grid(G, (unsigned)cdiv(N, 256));
@@ -177,11 +182,6 @@ int launch_linear_wgrad(const void* dY, const void* A, int64_t M, int N, int K, 
     else hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)dY, M, N, (float*)scratch);
     MAE_LAUNCH_CHECK();
     MAE_TRY(launch_sum_partials((const float*)scratch, G, N, db, nullptr, N, s));
-  }
-  if (dt == MAE_BF16) {
-    void* slab = scratch ? (char*)scratch + round_up((int64_t)COLSUM_BLOCKS * N * 4, 256) : nullptr;
-    const int r = mfma_linear_wgrad((const bf16*)dY, (const bf16*)A, M, N, K, dW, slab, s);
-    if (r != MFMA_UNSUPPORTED) return r;
   }
   // fallback: dW[n][k] = sum_m dY[m*N + n] * A[m*K + k]; reduction over M, split across gridDim.z when long
   const int64_t chunk = M <= 4096 ? M : 2048;

@@ -35,6 +35,17 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
   return 0.5f * (1.0f + copysignf(ea, x)) + x * 0.39894228040143267794f * e;
 }
 
+__device__ __forceinline__ void store8(float* p, const f32x4& a, const f32x4& b) { store4(p, a); store4(p + 4, b); }
+__device__ __forceinline__ void store8(bf16* p, const f32x4& a, const f32x4& b) {
+  *reinterpret_cast<bf16x8*>(p) = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+__device__ __forceinline__ void load8(const float* p, f32x4& a, f32x4& b) { a = load4(p); b = load4(p + 4); }
+__device__ __forceinline__ void load8(const bf16* p, f32x4& a, f32x4& b) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+  a = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  b = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+}
+
 struct EpiArgs {
   const float* bias;
   const void* aux;
@@ -125,36 +136,56 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
     }
   }
 
-  // epilogue: lane holds out[m][nb .. nb+3], m = tile row fr, nb = 4*fq inside each 16x16 tile
+  // epilogue.  After the MFMAs lane (fq, fr) holds, per 16x16 tile ni, 4 consecutive columns (4 fq ..) of row fr.
+  // One v_permlane16_swap per register pair (tiles 2j, 2j+1; lanes l <-> l+16) regroups that into 8 consecutive
+  // columns per lane: 16-byte bf16 stores, and the 4 lanes of a row cover 64 contiguous bytes per store.
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int j = 0; j < NI / 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mi][2 * j][r]), __float_as_uint(acc[mi][2 * j + 1][r]), false, false);
+        acc[mi][2 * j][r] = __uint_as_float(sw[0]);
+        acc[mi][2 * j + 1][r] = __uint_as_float(sw[1]);
+      }
+  const int gb = (fq & 1) ? 3 + fq : fq;  // 4-column group of this lane inside a 32-column half: {0,4,2,6}[fq]
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int64_t m = m0 + wm * 64 + mi * 16 + fr;
     if (m >= M) continue;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wn * (NI * 16) + ni * 16 + fq * 4;
+    for (int j = 0; j < NI / 2; ++j) {
+      const int n = n0 + wn * (NI * 16) + 32 * j + 4 * gb;
       const int64_t o = m * N + n;
-      f32x4 v = acc[mi][ni];
-      if (ep.bias) v += load4(ep.bias + n);
+      f32x4 v0 = acc[mi][2 * j], v1 = acc[mi][2 * j + 1];
+      if (ep.bias) { v0 += load4(ep.bias + n); v1 += load4(ep.bias + n + 4); }
       if (MODE == MAE_EPI_NONE) {
-        store4(reinterpret_cast<TO*>(ep.out) + o, v);
+        store8(reinterpret_cast<TO*>(ep.out) + o, v0, v1);
       } else if (MODE == MAE_EPI_GELU) {
-        f32x4 pre, act;
+        f32x4 a0, a1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pre[r] = to_f(from_f<TO>(v[r]));
-          act[r] = gelu_fast(pre[r]);
+          v0[r] = to_f(from_f<TO>(v0[r]));
+          v1[r] = to_f(from_f<TO>(v1[r]));
+          a0[r] = gelu_fast(v0[r]);
+          a1[r] = gelu_fast(v1[r]);
         }
-        store4(reinterpret_cast<TO*>(ep.out) + o, pre);
-        store4(reinterpret_cast<TO*>(ep.out2) + o, act);
+        store8(reinterpret_cast<TO*>(ep.out) + o, v0, v1);
+        store8(reinterpret_cast<TO*>(ep.out2) + o, a0, a1);
       } else if (MODE == MAE_EPI_RESID) {
-        v += load4(reinterpret_cast<const float*>(ep.aux) + o);
-        store4(reinterpret_cast<TO*>(ep.out) + o, v);
+        v0 += load4(reinterpret_cast<const float*>(ep.aux) + o);
+        v1 += load4(reinterpret_cast<const float*>(ep.aux) + o + 4);
+        store8(reinterpret_cast<TO*>(ep.out) + o, v0, v1);
       } else {
-        const f32x4 pre = load4(reinterpret_cast<const TO*>(ep.aux) + o);
+        f32x4 p0, p1;
+        load8(reinterpret_cast<const TO*>(ep.aux) + o, p0, p1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_fast(pre[r]);
-        store4(reinterpret_cast<TO*>(ep.out) + o, v);
+        for (int r = 0; r < 4; ++r) {
+          v0[r] *= gelu_grad_fast(p0[r]);
+          v1[r] *= gelu_grad_fast(p1[r]);
+        }
+        store8(reinterpret_cast<TO*>(ep.out) + o, v0, v1);
       }
     }
   }
@@ -208,8 +239,8 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
 // NI / KI: 16-wide tiles per wave along n / k (block tile = 32*NI x 32*KI), reduction step 64 rows of m
 template <int NI, int KI>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict__ dY, const bf16* __restrict__ X, int64_t M, int N,
-                                                         int K, float* __restrict__ out, int tiles_n, int tiles_k,
-                                                         int64_t m_chunk) {
+                                                         int K, float* __restrict__ out, float* __restrict__ db,
+                                                         int64_t split_stride, int tiles_n, int tiles_k, int64_t m_chunk) {
   constexpr int TNB = 32 * NI, TKB = 32 * KI, BR = 64;
   constexpr int Y_BYTES = BR * TN_RS, X_BYTES = BR * TN_RS;
   constexpr int YC = TNB / 8 * BR / 256;  // 16-byte chunks per thread for the dY tile (TNB/8 chunks per row)
@@ -251,11 +282,18 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
     }                                                                                         \
   }
 
-  f32x4 acc[KI][NI];
+  f32x4 acc[KI][NI], accb[NI];
 #pragma unroll
   for (int i = 0; i < KI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NI; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient = column sums of dY: one extra MFMA per n-tile against an all-ones operand, done by the waves
+  // that own the first k tile (wave-uniform condition)
+  const bool do_bias = db != nullptr && k0 == 0 && wk == 0;
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
 
   // transposed-read address of this lane inside a 32-row k-substep: rows 16h + 4g + q, columns cb + 4p .. 4p+3
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
@@ -290,10 +328,18 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ki], yf[ni], acc[ki][ni], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[ni], accb[ni], 0, 0, 0);
+      }
     }
   }
   // D[i = k][j = n]: lane holds n = tile col (lane&15), k = 4*(lane>>4) + r -> 16-byte store along k
-  float* o = out + (int64_t)split * N * K;
+  float* o = out + (int64_t)split * split_stride;
+  if (do_bias && lane < 16) {  // every row of the ones-product is the same column sum: take row 0
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) db[(int64_t)split * split_stride + n0 + wn * NI * 16 + ni * 16 + lane] = accb[ni][0];
+  }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int n = n0 + wn * NI * 16 + ni * 16 + (lane & 15);
@@ -305,11 +351,13 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t n4, float* __restrict__ out) {
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+// ordered (deterministic) sum of the per-split slabs: [S][N*K weight partials | N bias partials]
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t stride4, int64_t nw4,
+                                                          int64_t nb4, float* __restrict__ dW, float* __restrict__ db) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nw4 + nb4; i += (int64_t)gridDim.x * 256) {
     f32x4 acc = load4(slabs + i * 4);
-    for (int s = 1; s < S; ++s) acc += load4(slabs + ((int64_t)s * n4 + i) * 4);
-    store4(out + i * 4, acc);
+    for (int s = 1; s < S; ++s) acc += load4(slabs + ((int64_t)s * stride4 + i) * 4);
+    if (i < nw4) store4(dW + i * 4, acc); else store4(db + (i - nw4) * 4, acc);
   }
 }
 
@@ -324,38 +372,41 @@ static int wgrad_splits(int64_t M, int N, int K) {
 int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K) {
   if (N % 64 != 0 || K % 64 != 0) return 0;
   const int S = wgrad_splits(M, N, K);
-  return S > 1 ? round_up((int64_t)S * N * K * 4, 256) : 0;
+  return S > 1 ? round_up((int64_t)S * ((int64_t)N * K + N) * 4, 256) : 0;
 }
 
 template <int NI, int KI>
-static int launch_tn(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* out, int S, int64_t m_chunk, hipStream_t s) {
+static int launch_tn(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* out, float* db, int64_t split_stride, int S,
+                     int64_t m_chunk, hipStream_t s) {
   const int tiles_n = N / (32 * NI), tiles_k = K / (32 * KI);
   const size_t lds = 4 * 64 * TN_RS;
   auto kern = gemm_tn_kernel<NI, KI>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(256), lds, s, dY, X, M, N, K, out, tiles_n, tiles_k, m_chunk);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(256), lds, s, dY, X, M, N, K, out, db, split_stride, tiles_n, tiles_k, m_chunk);
   MAE_LAUNCH_CHECK();
   return 0;
 }
 
-int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* dW, void* slab, hipStream_t s) {
+int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* dW, float* db, void* slab, hipStream_t s) {
   if (N % 64 != 0 || K % 64 != 0 || M < 1) return MFMA_UNSUPPORTED;
-  if ((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)slab) & 15) != 0) return MFMA_UNSUPPORTED;
+  if ((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)db | (uintptr_t)slab) & 15) != 0) return MFMA_UNSUPPORTED;
   const int S = wgrad_splits(M, N, K);
   if (S > 1 && !slab) return MFMA_UNSUPPORTED;
   const int64_t m_chunk = round_up(cdiv(M, S), 64);
+  const int64_t stride = S > 1 ? (int64_t)N * K + N : 0;
   float* out = S > 1 ? reinterpret_cast<float*>(slab) : dW;
+  float* dbo = !db ? nullptr : (S > 1 ? out + (int64_t)N * K : db);
   const bool n128 = N % 128 == 0, k128 = K % 128 == 0;
   int r;
-  if (n128 && k128) r = launch_tn<4, 4>(dY, X, M, N, K, out, S, m_chunk, s);
-  else if (n128) r = launch_tn<4, 2>(dY, X, M, N, K, out, S, m_chunk, s);
-  else if (k128) r = launch_tn<2, 4>(dY, X, M, N, K, out, S, m_chunk, s);
-  else r = launch_tn<2, 2>(dY, X, M, N, K, out, S, m_chunk, s);
+  if (n128 && k128) r = launch_tn<4, 4>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
+  else if (n128) r = launch_tn<4, 2>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
+  else if (k128) r = launch_tn<2, 4>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
+  else r = launch_tn<2, 2>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
   if (r) return r;
   if (S > 1) {
-    const int64_t n4 = (int64_t)N * K / 4;
-    const int grid = (int)std::min<int64_t>(cdiv(n4, 256), 2048);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)slab, S, n4, dW);
+    const int64_t nw4 = (int64_t)N * K / 4, nb4 = db ? N / 4 : 0;
+    const int grid = (int)std::min<int64_t>(cdiv(nw4 + nb4, 256), 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)slab, S, stride / 4, nw4, nb4, dW, db);
     MAE_LAUNCH_CHECK();
   }
   return 0;
