@@ -1,0 +1,82 @@
+"""World-size-2 data-parallel logic on CPU (gloo): rank-sliced images and noise, grad_scale = 1/world, ONE all-reduce
+of the flat gradient arena, identical clip + AdamW on every rank == the single-process full-batch step.  The compute
+stand-in here is the CPU oracle (no GPU in this container); on the GPU box the same functions wrap the native step."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    torch.set_float32_matmul_precision("highest")
+    from oracle import mae_oracle as O
+    from ssrl_vit_mae_jepa_amd import dist as mdist
+    r, w = mdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg = O.MAEConfig(image_size=32, patch_size=8, in_chans=3, embed_dim=48, depth=1, num_heads=2, decoder_embed_dim=64,
+                      decoder_depth=1, decoder_num_heads=2)
+    params = O.init_params(cfg, 73); O.randomize_params(params)
+    B = 8
+    images = O.synthetic_images(B, cfg)
+    noise = mdist.global_noise(B, cfg.sequence_length, 73, 0, torch.device("cpu"))
+    my_images, my_noise = mdist.shard_rows(images, rank, world), mdist.shard_rows(noise, rank, world)
+    loss, grads, aux = O.loss_and_grads(params, cfg, my_images, my_noise)
+    names = list(grads)
+    flat = torch.cat([g.reshape(-1) for g in grads.values()]) / world  # grad_scale = 1/world
+    mdist.allreduce_sum_(flat)                                        # the single collective of the step
+    # replicated clip + AdamW
+    off, g2 = 0, {}
+    for n in names:
+        g2[n] = flat[off:off + grads[n].numel()].view_as(grads[n]).clone(); off += grads[n].numel()
+    total, _ = O.clip_grad_norm(g2, 1.0)
+    O.adamw_step(params, g2, {}, 1e-3, 1)
+    torch.save({"flat": flat, "total": total, "keep": aux["idx_keep"], "p": params["decoder.decoder_pred.weight"]}, f"{out_dir}/r{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_step(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import mae_oracle as O
+    from ssrl_vit_mae_jepa_amd import dist as mdist
+    torch.set_float32_matmul_precision("highest")
+    cfg = O.MAEConfig(image_size=32, patch_size=8, in_chans=3, embed_dim=48, depth=1, num_heads=2, decoder_embed_dim=64,
+                      decoder_depth=1, decoder_num_heads=2)
+    params = O.init_params(cfg, 73); O.randomize_params(params)
+    images = O.synthetic_images(8, cfg)
+    noise = mdist.global_noise(8, cfg.sequence_length, 73, 0, torch.device("cpu"))
+    loss, grads, aux = O.loss_and_grads(params, cfg, images, noise)
+    flat = torch.cat([g.reshape(-1) for g in grads.values()])
+    total, _ = O.clip_grad_norm(grads, 1.0)
+    O.adamw_step(params, grads, {}, 1e-3, 1)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["flat"], r1["flat"])                                   # every rank holds the same reduced grads
+    assert torch.allclose(r0["flat"], flat, rtol=1e-4, atol=1e-7)                # == full-batch gradient (mean of means)
+    assert abs(float(r0["total"]) - float(total)) < 1e-4 * float(total)          # global norm, not per-rank norm
+    assert torch.equal(torch.cat([r0["keep"], r1["keep"]]), aux["idx_keep"])     # rank-sliced noise -> identical masks
+    assert torch.allclose(r0["p"], params["decoder.decoder_pred.weight"], rtol=1e-4, atol=1e-6) and torch.equal(r0["p"], r1["p"])
+
+
+def test_shard_rows_rejects_ragged_batches():
+    from ssrl_vit_mae_jepa_amd import dist as mdist
+    with pytest.raises(ValueError):
+        mdist.shard_rows(torch.zeros(7, 3), 0, 2)
+    t = torch.arange(12).reshape(6, 2)
+    assert torch.equal(torch.cat([mdist.shard_rows(t, r, 3) for r in range(3)]), t)

@@ -195,3 +195,58 @@ def test_full_size_properties_vits8_b2000(dev):
     assert rel_err(ga + model.flat_grads, g1) < 2e-2
     # (5) frozen position tables and the unreachable encoder mask token are outside the optimizer range
     assert model.engine.trainable_elems < model.engine.arena_elems
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# committed golden vectors (tests/golden/mae_micro.npz) and the caller of the path (pretrain CLI)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,r", [("b2_r75", 0.75), ("b5_r50", 0.5)])
+def test_fp32_engine_matches_committed_golden(dev, tag, r):
+    import numpy as np
+    from pathlib import Path
+    gold = np.load(Path(__file__).parent / "golden" / "mae_micro.npz")
+    T = lambda k: torch.from_numpy(gold[f"{tag}/{k}"])  # noqa: E731
+    model, params = build(MICRO, "fp32", dev, r)
+    loss, keep, mask = model.loss_and_grads(T("images").to(dev), T("noise").to(dev), return_indices=True)
+    assert torch.equal(keep.cpu(), T("idx_keep")) and torch.equal(mask.cpu(), T("idx_mask"))
+    assert abs(loss.item() - float(T("loss"))) <= 1e-4 * float(T("loss"))
+    g = model.named_flat_views(model.flat_grads)
+    names = O.trainable_names(MICRO)
+    assert rel_err(torch.stack([g[n].norm() for n in names]), T("grad_norms")) < 2e-4
+    for k in gold.files:
+        if k.startswith(f"{tag}/grad/"):
+            assert rel_err(g[k.split("/", 2)[2]], torch.from_numpy(gold[k])) < 2e-4, k
+    assert torch.equal(model.patchify_gather(T("images").to(dev), mask).cpu(), T("target"))
+    # tie case: equal keys ordered by index
+    noise, stable = torch.from_numpy(gold["ties/noise"]), torch.from_numpy(gold["ties/order_stable"])
+    m17 = MaskedAutoencoder(dict(image_size=32, patch_size=8, mask_ratio=0.75, engine_precision="fp32"),
+                            dict(embed_dim=48, depth=1, num_heads=2), dict(decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2)).to(dev)
+    k2, m2 = m17.random_token_mask(3, noise.to(dev))
+    assert torch.equal(torch.cat([k2, m2], 1).cpu(), stable)
+
+
+def test_pretrain_cli_synthetic_run_and_resume(dev, tmp_path, monkeypatch):
+    import yaml
+    from pathlib import Path
+    from scripts.training import pretrain_mae as cli
+    cfg = yaml.safe_load(open(Path(__file__).resolve().parents[1] / "configs" / "mae.yaml"))
+    cfg["pretrain"].update(batch_size=32, total_epochs=3, warmup_epochs=2)
+    cfg["logging"]["output_dir_base"] = str(tmp_path / "outputs")
+    cfg_path = tmp_path / "mae.yaml"
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    monkeypatch.chdir(tmp_path)
+    cli.main(["--config", str(cfg_path), "--output_dir_suffix", "t", "--synthetic_images", "128", "--max_epochs", "2"])
+    out = tmp_path / "outputs" / "pretrain" / "t"
+    assert (out / "config.yaml").exists() and (out / "vit-mae.pt").exists()
+    assert (out / "checkpoints" / "last.ckpt").exists() and (out / "checkpoints" / "best.ckpt").exists()
+    ck = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
+    assert ck["epoch"] == 1 and all(k.startswith("model.") for k in ck["state_dict"])
+    assert "model.encoder.vit.blocks.0.attn.qkv.weight" in ck["state_dict"] and ck["optimizer_states"][0]["step"] == ck["global_step"]
+    raw = torch.load(out / "vit-mae.pt", weights_only=True)
+    assert list(raw) == list(O.param_shapes(O.YAML_TINY))  # raw state_dict, reference key names
+    lines = (out / "logs" / "metrics.jsonl").read_text().strip().splitlines()
+    assert len(lines) == 2
+    cli.main(["--config", str(cfg_path), "--output_dir_suffix", "t", "--synthetic_images", "128",
+              "--resume_from", str(out / "checkpoints" / "last.ckpt")])
+    ck2 = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
+    assert ck2["epoch"] == 2 and ck2["global_step"] > ck["global_step"]
