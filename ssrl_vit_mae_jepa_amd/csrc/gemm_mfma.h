@@ -11,6 +11,9 @@ constexpr int MFMA_UNSUPPORTED = -7777;
 // out[M,N] = A[M,K] * W[N,K]^T with the Epi epilogues; needs K % 32 == 0, N % 16 == 0
 int mfma_linear_fwd(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& epi, hipStream_t s);
 
+// persistent LDS-DMA ring variant (k_gemm_mfma2.hip): NONE / GELU epilogues, N % 128 == 0, K % 64 == 0, K >= 192
+int mfma_linear_fwd_v2(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& epi, hipStream_t s);
+
 // dW[N,K] = dY[M,N]^T * A[M,K] (fp32, written)
 int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K);
 // also db[N] = column sums of dY when db != null

@@ -5,6 +5,7 @@
 // decoder_embed/decoder_pred and the patch-embed conv viewed as a Linear over (c,py,px) patch vectors.
 #include "kernels.h"
 #include "gemm_mfma.h"
+#include <cstdlib>
 
 namespace mae {
 
@@ -119,6 +120,11 @@ int launch_linear_fwd(const void* A, const void* W, int64_t M, int N, int K, int
   MAE_REQUIRE(A && W && M > 0 && N > 0 && K > 0, "linear_fwd: bad arguments");
   MAE_TRY(check_epi(e, dt, "linear_fwd"));
   if (dt == MAE_BF16) {
+    const char* var = getenv("MAE_GEMM_NT");  // "v1" pins the per-tile kernel (A/B runs in tools/gemm_bench.py)
+    if (!(var && var[0] == 'v' && var[1] == '1')) {
+      const int r2 = mfma_linear_fwd_v2((const bf16*)A, (const bf16*)W, M, N, K, e, s);
+      if (r2 != MFMA_UNSUPPORTED) return r2;
+    }
     const int r = mfma_linear_fwd((const bf16*)A, (const bf16*)W, M, N, K, e, s);
     if (r != MFMA_UNSUPPORTED) return r;
     if (e.out_dt == MAE_BF16) return run_generic<bf16, bf16>(A, K, 1, W, 1, K, M, N, K, e, s);

@@ -1,0 +1,304 @@
+// Persistent bf16 MFMA NT GEMM for gfx950 with an LDS-DMA ring (v2 of gemm_nt_kernel).
+//
+//   out[M,N] = A[M,K] * W[N,K]^T (+bias) with the NONE / GELU epilogues, M = batch*tokens (huge), K = 192..1536.
+//
+// Why: with K = 384 a 128x128 tile lives for only 6 K-steps, so a one-tile register prefetch leaves every CU waiting
+// on memory latency (v1 measured ~5 TB/s of L2->CU traffic, 0.3-0.7 PF).  Here one 512-thread workgroup per CU walks a
+// list of 256x128 tiles and keeps a 3-stage ring (3 x 48 KiB of LDS) filled by `global_load_lds_dwordx4` two K-steps
+// ahead, ACROSS tile boundaries: 96 KiB in flight per CU, no pipeline drain between tiles, half the operand traffic per
+// flop of the 128x128 tile.
+//   * LDS image is lane-linear per DMA (8 rows x 128 B per wave instruction); the bank-conflict swizzle is applied
+//     on the per-lane SOURCE address and again on the fragment read (same involution, chunk ^ (row & 7)).
+//   * one raw s_barrier per K-step; waits are counted (`s_waitcnt vmcnt(N)`, never 0 in steady state): N = the vector
+//     memory operations issued after the stage being waited for = the next stage's DMAs (+ the previous tile's
+//     epilogue stores for the first two K-steps of a tile, when that tile was full so all its stores were issued).
+//   * the bias slice of the tile rides along as one 4-byte DMA per K-step into a double-buffered LDS strip, so the
+//     epilogue needs no ordinary global load (hipcc drains the DMA queue with vmcnt(0) before using one).
+//   * blocks are XCD-remapped so the 32 CUs of an XCD work on adjacent tiles (shared A panels / W tiles in L2).
+#include "gemm_mfma.h"
+
+namespace mae {
+
+namespace {
+
+constexpr int BM2 = 256, BK2 = 64;
+
+template <int NI>
+struct Geo {  // NI = 16-column MFMA tiles per wave along N (2 waves along N): BN = 32 NI = 128 or 192
+  static constexpr int BN = 32 * NI;
+  static constexpr int STAGE = (BM2 + BN) * BK2 * 2;              // A rows first, then W rows, 128 B per row
+  static constexpr int NSTAGE = NI == 4 ? 3 : 2;                   // 3 x 48 KiB or 2 x 56 KiB
+  static constexpr int AHEAD = NSTAGE - 1;                         // K-steps of DMA in flight during a compute phase
+  static constexpr int BIAS_OFF = NSTAGE * STAGE;                  // [2 tiles][BN] floats
+  static constexpr int LDS = BIAS_OFF + 2 * BN * 4;
+  static constexpr int GPW = (BM2 + BN) / 8 / 8;                   // 1 KiB DMA groups (8 rows) per wave and stage: 6 or 7
+  static constexpr int NBIAS = BN / 64;                            // 256-byte bias DMAs per wave at the first K-step of a tile
+};
+
+__device__ __forceinline__ float gelu_fast2(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  return 0.5f * x * (1.0f + copysignf(1.0f - poly * e, x));
+}
+
+__device__ __forceinline__ float gelu_grad_fast2(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  return 0.5f * (1.0f + copysignf(1.0f - poly * e, x)) + x * 0.39894228040143267794f * e;
+}
+__device__ __forceinline__ void ld8(const float* p, f32x4& a, f32x4& b) { a = load4(p); b = load4(p + 4); }
+__device__ __forceinline__ void ld8(const bf16* p, f32x4& a, f32x4& b) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+  a = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  b = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+}
+__device__ __forceinline__ void st8(float* p, const f32x4& a, const f32x4& b) { store4(p, a); store4(p + 4, b); }
+__device__ __forceinline__ void st8(bf16* p, const f32x4& a, const f32x4& b) {
+  *reinterpret_cast<bf16x8*>(p) = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+
+__device__ __forceinline__ void glds16(const bf16* src, char* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const float* src, char* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+}
+
+__device__ __forceinline__ int64_t xcd_remap2(int64_t bid, int64_t nb) {
+  const int64_t q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+}  // namespace
+
+// MODE: any MAE_EPI_*.  RESID / DGELU read their (M,N) side input with ordinary loads in the epilogue.
+template <int MODE, class TO, bool HAS_BIAS, int NI>
+__global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M, int N,
+                                                          int K, const float* __restrict__ bias, const void* __restrict__ aux,
+                                                          TO* __restrict__ out, TO* __restrict__ out2, int tiles_m, int tiles_n) {
+  using G_ = Geo<NI>;
+  constexpr int BN = G_::BN, STAGE = G_::STAGE, NSTAGE = G_::NSTAGE, AHEAD = G_::AHEAD, GPW = G_::GPW;
+  constexpr int NB = HAS_BIAS ? G_::NBIAS : 0;
+  constexpr int STORE8 = sizeof(TO) == 2 ? 1 : 2;                                // store instructions per 8 outputs
+  constexpr int E = 4 * (NI / 2) * STORE8 * (MODE == MAE_EPI_GELU ? 2 : 1);      // epilogue stores per wave (full tile)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int G = gridDim.x, T = tiles_m * tiles_n;
+  const int vb = (int)xcd_remap2(blockIdx.x, G);
+  const int ntile = (T - vb + G - 1) / G;
+  const int nk = K / BK2;
+  const int nsteps = ntile * nk;
+
+  // ---- producer side: this wave's DMA groups of a stage (group g < 32: A rows 8g.., else W rows 8(g-32)..)
+  const int r8 = lane >> 3;
+  const int src_chunk = ((lane & 7) ^ r8) * 8;  // swizzled source chunk (elements) for LDS slot lane&7 of row r8
+  const bf16 *p0, *p1, *p2, *p3, *p4, *p5, *p6 = nullptr;
+  const float* pbias = bias;
+  int is_tile = 0, is_k = 0, is_stage = 0;
+  auto src_ptr = [&](int q, int64_t m0, int n0) -> const bf16* {
+    const int g = wave * GPW + q;
+    if (g < BM2 / 8) {
+      int64_t row = m0 + g * 8 + r8;
+      row = row < M ? row : M - 1;  // clamp: rows past M are loaded (valid memory) and never stored
+      return A + row * K + src_chunk;
+    }
+    return W + (int64_t)(n0 + (g - BM2 / 8) * 8 + r8) * K + src_chunk;
+  };
+  auto set_tile = [&](int ord) {
+    const int t = vb + ord * G;
+    const int64_t m0 = (int64_t)(t / tiles_n) * BM2;
+    const int n0 = (t % tiles_n) * BN;
+    p0 = src_ptr(0, m0, n0); p1 = src_ptr(1, m0, n0); p2 = src_ptr(2, m0, n0);
+    p3 = src_ptr(3, m0, n0); p4 = src_ptr(4, m0, n0); p5 = src_ptr(5, m0, n0);
+    if (GPW > 6) p6 = src_ptr(6, m0, n0);
+    if (HAS_BIAS) pbias = bias + n0 + lane;
+  };
+  auto issue = [&]() {
+    char* dst = smem + is_stage * STAGE + wave * (GPW * 1024);
+    const int ko = is_k * BK2;
+    glds16(p0 + ko, dst);
+    glds16(p1 + ko, dst + 1024);
+    glds16(p2 + ko, dst + 2048);
+    glds16(p3 + ko, dst + 3072);
+    glds16(p4 + ko, dst + 4096);
+    glds16(p5 + ko, dst + 5120);
+    if (GPW > 6) glds16(p6 + ko, dst + 6144);
+    if (HAS_BIAS && is_k == 0) {  // the tile's bias strip rides with its first K-step (every wave writes the same bytes)
+      char* bdst = smem + G_::BIAS_OFF + (is_tile & 1) * (BN * 4);
+#pragma unroll
+      for (int i = 0; i < G_::NBIAS; ++i) glds4(pbias + 64 * i, bdst + 256 * i);
+    }
+    is_stage = is_stage == NSTAGE - 1 ? 0 : is_stage + 1;
+    if (++is_k == nk) {
+      is_k = 0;
+      if (++is_tile < ntile) set_tile(is_tile);
+    }
+  };
+
+  f32x4 acc[4][NI];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  set_tile(0);
+  issue();
+  if (AHEAD > 1 && nsteps > 1) issue();
+
+  int ct = 0, ck = 0, cs = 0;
+  bool prev_full = false;
+  const int gb = (fq & 1) ? 3 + fq : fq;
+  for (int step = 0; step < nsteps; ++step) {
+    // ---- wait for this step's DMAs: allowed outstanding = vector-memory ops issued after them
+    //      = the next AHEAD-1 steps' DMAs (+ the bias DMAs when that step opens a tile)
+    //        (+ the previous tile's epilogue stores, when that tile was full so every store was issued)
+    const bool after_epi = ct > 0 && prev_full && ck < AHEAD;
+    if (AHEAD == 2) {
+      if (step + 1 >= nsteps) wait_vm<0>();
+      else if (ck == nk - 1) wait_vm<GPW + NB>();   // the next step is a tile's first: it carried the bias DMAs
+      else if (after_epi) wait_vm<GPW + E>();
+      else wait_vm<GPW>();
+    } else {
+      if (after_epi) wait_vm<E>();
+      else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (step + AHEAD < nsteps) issue();  // refills the stage every wave finished reading in the previous iteration
+
+    const char* a_base = smem + cs * STAGE + (wm * 64 + fr) * 128;
+    const char* b_base = smem + cs * STAGE + BM2 * 128 + (wn * (NI * 16) + fr) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int sw = ((ks * 4 + fq) ^ (fr & 7)) << 4;
+      bf16x8 af[4], bfr[NI];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(b_base + ni * 16 * 128 + sw);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    cs = cs == NSTAGE - 1 ? 0 : cs + 1;
+
+    if (++ck == nk) {
+      // ---- epilogue of tile `ct`: regroup to 8 consecutive columns per lane (see gemm_nt_kernel), store
+      const int t = vb + ct * G;
+      const int64_t m0 = (int64_t)(t / tiles_n) * BM2;
+      const int n0 = (t % tiles_n) * BN;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int j = 0; j < NI / 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[mi][2 * j][r]), __float_as_uint(acc[mi][2 * j + 1][r]), false, false);
+            acc[mi][2 * j][r] = __uint_as_float(sw[0]);
+            acc[mi][2 * j + 1][r] = __uint_as_float(sw[1]);
+          }
+      const float* sbias = reinterpret_cast<const float*>(smem + G_::BIAS_OFF + (ct & 1) * (BN * 4)) + wn * (NI * 16);
+#pragma unroll
+      for (int j = 0; j < NI / 2; ++j) {
+        const int nl = 32 * j + 4 * gb;  // column inside the wave's NI*16
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (HAS_BIAS) { b0 = load4(sbias + nl); b1 = load4(sbias + nl + 4); }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int64_t m = m0 + wm * 64 + mi * 16 + fr;
+          if (m < M) {
+            const int64_t o = m * N + n0 + wn * (NI * 16) + nl;
+            f32x4 v0 = acc[mi][2 * j] + b0, v1 = acc[mi][2 * j + 1] + b1;
+            if (MODE == MAE_EPI_GELU) {
+              f32x4 a0, a1;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v0[r] = to_f(from_f<TO>(v0[r]));
+                v1[r] = to_f(from_f<TO>(v1[r]));
+                a0[r] = gelu_fast2(v0[r]);
+                a1[r] = gelu_fast2(v1[r]);
+              }
+              st8(out + o, v0, v1);
+              st8(out2 + o, a0, a1);
+            } else if (MODE == MAE_EPI_RESID) {
+              v0 += load4(reinterpret_cast<const float*>(aux) + o);
+              v1 += load4(reinterpret_cast<const float*>(aux) + o + 4);
+              st8(out + o, v0, v1);
+            } else if (MODE == MAE_EPI_DGELU) {
+              f32x4 q0, q1;
+              ld8(reinterpret_cast<const TO*>(aux) + o, q0, q1);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v0[r] *= gelu_grad_fast2(q0[r]);
+                v1[r] *= gelu_grad_fast2(q1[r]);
+              }
+              st8(out + o, v0, v1);
+            } else {
+              st8(out + o, v0, v1);
+            }
+          }
+          acc[mi][2 * j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[mi][2 * j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      prev_full = m0 + BM2 <= M;
+      ck = 0;
+      ++ct;
+    }
+  }
+}
+
+template <int MODE, class TO, int NI>
+static int launch_nt2(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
+  using G_ = Geo<NI>;
+  const int64_t T = cdiv(M, BM2) * (N / G_::BN);
+  MAE_REQUIRE(T < (1ll << 30), "gemm: too many tiles");
+  const int tiles_m = (int)cdiv(M, BM2), tiles_n = N / G_::BN;
+  const int grid = (int)std::min<int64_t>(T, 256);
+  if (e.bias) {
+    auto kern = gemm_nt2_kernel<MODE, TO, true, NI>;
+    MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
+  } else {
+    auto kern = gemm_nt2_kernel<MODE, TO, false, NI>;
+    MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
+  }
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int MODE, class TO>
+static int launch_nt2_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
+  if (N % 192 == 0) return launch_nt2<MODE, TO, 6>(A, W, M, N, K, e, s);
+  return launch_nt2<MODE, TO, 4>(A, W, M, N, K, e, s);
+}
+
+int mfma_linear_fwd_v2(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
+  if (K % 64 != 0 || K < 192 || (N % 128 != 0 && N % 192 != 0) || M < 1) return MFMA_UNSUPPORTED;
+  if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)e.out | (uintptr_t)e.out2 | (uintptr_t)e.bias | (uintptr_t)e.aux) & 15) != 0) return MFMA_UNSUPPORTED;
+  const bool f32out = e.out_dt == MAE_F32;
+  switch (e.mode) {
+    case MAE_EPI_NONE: return f32out ? launch_nt2_ni<MAE_EPI_NONE, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_NONE, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_GELU: return f32out ? launch_nt2_ni<MAE_EPI_GELU, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_GELU, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_RESID: return f32out ? launch_nt2_ni<MAE_EPI_RESID, float>(A, W, M, N, K, e, s) : MFMA_UNSUPPORTED;
+    case MAE_EPI_DGELU: return f32out ? launch_nt2_ni<MAE_EPI_DGELU, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_DGELU, bf16>(A, W, M, N, K, e, s);
+    default: return MFMA_UNSUPPORTED;
+  }
+}
+
+}  // namespace mae

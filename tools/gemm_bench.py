@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the Linear GEMM kernels on the pretrain-step shapes (GPU box).  Interleaved A/B of the NT kernel
+variants in one process (MAE_GEMM_NT=v1|v2), random bf16 data, reports TFLOP/s and GB/s and checks the variants agree
+bit for bit.    python tools/gemm_bench.py [--rounds 5]"""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+from tests.util import BF16, F32, TDT, check, lib, stream, _ptr  # noqa: E402
+
+SHAPES = [  # name, M, N, K, epilogue, out dtype
+    ("enc qkv fwd", 72000, 1152, 384, "none", BF16),
+    ("enc fc1 fwd (gelu)", 72000, 1536, 384, "gelu", BF16),
+    ("enc proj fwd", 72000, 384, 384, "none", BF16),
+    ("enc fc2 fwd", 72000, 384, 1536, "none", BF16),
+    ("enc fc2 dgrad (dgelu)", 72000, 1536, 384, "dgelu", BF16),
+    ("enc qkv dgrad", 72000, 384, 1152, "none", BF16),
+    ("enc proj fwd resid", 72000, 384, 384, "resid", F32),
+    ("dec qkv fwd", 290000, 576, 192, "none", BF16),
+    ("dec fc1 fwd (gelu)", 290000, 768, 192, "gelu", BF16),
+    ("dec fc2 fwd", 290000, 192, 768, "none", BF16),
+    ("patch embed", 72000, 384, 192, "none", F32),
+    ("pred head", 218000, 192, 192, "none", F32),
+]
+MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--variants", default="v1,v2")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    variants = args.variants.split(",")
+    g = torch.Generator(device=dev).manual_seed(1)
+    for name, M, N, K, epi, odt in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        W = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.rand(N, device=dev, generator=g)
+        aux = None
+        if epi == "resid":
+            aux = torch.rand(M, N, device=dev, generator=g)
+        elif epi == "dgelu":
+            aux = (torch.rand(M, N, device=dev, generator=g) * 4 - 2).to(TDT[odt])
+        outs, times = {}, {v: [] for v in variants}
+        for v in variants:
+            outs[v] = (torch.empty(M, N, dtype=TDT[odt], device=dev), torch.empty(M, N, dtype=TDT[odt], device=dev))
+
+        def run(v):
+            os.environ["MAE_GEMM_NT"] = v
+            o, o2 = outs[v]
+            check(lib.mae_linear_fwd(_ptr(A), _ptr(W), _ptr(bias), M, N, K, BF16, MODE[epi], odt, _ptr(o), _ptr(o2) if epi == "gelu" else None,
+                                     _ptr(aux) if aux is not None else None, stream(dev)))
+        for v in variants:
+            run(v)
+        torch.cuda.synchronize()
+        for _ in range(args.rounds):
+            for v in variants:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); run(v); e1.record(); torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) * 1e3)
+        osz = 4 if odt == F32 else 2
+        nbytes = M * K * 2 + N * K * 2 + M * N * osz * (2 if epi == "gelu" else 1) + (M * N * (4 if epi == "resid" else osz) if aux is not None else 0)
+        line = f"{name:24s} M={M} N={N} K={K}"
+        for v in variants:
+            t = sorted(times[v])[len(times[v]) // 2]
+            line += f" | {v}: {t:7.1f} us {2 * M * N * K / t / 1e6:6.0f} TF/s {nbytes / t / 1e3:5.0f} GB/s"
+        if len(variants) == 2:
+            same = torch.equal(outs[variants[0]][0], outs[variants[1]][0]) and (epi != "gelu" or torch.equal(outs[variants[0]][1], outs[variants[1]][1]))
+            line += f" | bitwise-equal={same}"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
