@@ -15,7 +15,7 @@ LIB_PATH = _HERE / "lib" / "libmae_hip.so"
 
 MAE_F32, MAE_BF16 = 0, 1
 PARAM_TRAINABLE, PARAM_FROZEN, PARAM_UNUSED, PARAM_MATRIX = 1, 2, 4, 8
-EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU = 0, 1, 2, 3
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 1
 
 

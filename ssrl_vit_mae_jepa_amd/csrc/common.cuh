@@ -92,4 +92,17 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// bf16-path GELU: erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7), one v_exp + one v_rcp shared by value and slope
+__device__ __forceinline__ void gelu_fast_pair(float x, float& act, float& slope) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float e = __expf(-z * z);  // exp(-x^2/2)
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+  act = x * cdf;
+  slope = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+__device__ __forceinline__ float gelu_fast(float x) { float a, g; gelu_fast_pair(x, a, g); return a; }
+__device__ __forceinline__ float gelu_grad_fast(float x) { float a, g; gelu_fast_pair(x, a, g); return g; }
+
 }  // namespace mae

@@ -273,7 +273,7 @@ static int block_forward(const Ctx& c, const BlockRefs& r, const LayerBufs& b, i
   RUN(TK_ATTN_FWD, 4.0 * Bn * heads * (double)T * T * hd, M * 4 * d * c.as, launch_attention_fwd(c.buf<>(b.qkv), Bn, T, heads, hd, c.act, c.buf<>(b.att), c.buf<float>(b.lse), s));
   MAE_TRY(linear(c, c.buf<>(b.att), r.proj_w, r.proj_b, M, d, d, MAE_EPI_RESID, MAE_F32, c.buf<>(b.x_mid), nullptr, c.buf<>(x_in)));
   RUN(TK_LN_FWD, 0, M * d * (4 + c.as), launch_layernorm_fwd(c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.P(r.ln2_b), eps, M, d, c.act, c.buf<>(b.ln2), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), s));
-  MAE_TRY(linear(c, c.buf<>(b.ln2), r.fc1_w, r.fc1_b, M, hid, d, MAE_EPI_GELU, c.act, c.buf<>(b.fc1_pre), c.buf<>(b.fc1_act), nullptr));
+  MAE_TRY(linear(c, c.buf<>(b.ln2), r.fc1_w, r.fc1_b, M, hid, d, MAE_EPI_GELU_GRAD, c.act, c.buf<>(b.fc1_pre), c.buf<>(b.fc1_act), nullptr));  // fc1_pre holds gelu'(pre)
   MAE_TRY(linear(c, c.buf<>(b.fc1_act), r.fc2_w, r.fc2_b, M, d, hid, MAE_EPI_RESID, MAE_F32, c.buf<>(x_out), nullptr, c.buf<>(b.x_mid)));
   return 0;
 }
@@ -288,7 +288,7 @@ static int block_backward(const Ctx& c, const Plan& pl, const BlockRefs& r, cons
   float* lnp = c.buf<float>(pl.ln_partial);
   // MLP branch
   MAE_TRY(wgrad(c, pl, dres_c, c.buf<>(b.fc1_act), M, d, hid, r.fc2_w, r.fc2_b));
-  MAE_TRY(dgrad(c, dres_c, r.fc2_w, M, d, hid, MAE_EPI_DGELU, c.buf<>(pl.d_hidden), c.buf<>(b.fc1_pre)));
+  MAE_TRY(dgrad(c, dres_c, r.fc2_w, M, d, hid, MAE_EPI_MUL, c.buf<>(pl.d_hidden), c.buf<>(b.fc1_pre)));
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_hidden), c.buf<>(b.ln2), M, hid, d, r.fc1_w, r.fc1_b));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_hidden), r.fc1_w, M, hid, d, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
   RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), M, d, 1, dres, dres_c, c.Gp(r.ln2_w), c.Gp(r.ln2_b), lnp, s));

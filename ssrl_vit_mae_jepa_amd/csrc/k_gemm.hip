@@ -31,8 +31,14 @@ struct EpiDev {
       out2[o] = from_f<TO>(gelu_erf(to_f(pre)));  // activation of the value as stored (bf16-rounded in bf16 mode)
     } else if (mode == MAE_EPI_RESID) {
       out[o] = from_f<TO>(acc + reinterpret_cast<const float*>(aux)[o]);
-    } else {  // MAE_EPI_DGELU
+    } else if (mode == MAE_EPI_DGELU) {
       out[o] = from_f<TO>(acc * gelu_erf_grad(to_f(reinterpret_cast<const TO*>(aux)[o])));
+    } else if (mode == MAE_EPI_GELU_GRAD) {
+      const float pre = to_f(from_f<TO>(acc));
+      out[o] = from_f<TO>(gelu_erf_grad(pre));
+      out2[o] = from_f<TO>(gelu_erf(pre));
+    } else {  // MAE_EPI_MUL
+      out[o] = from_f<TO>(acc * to_f(reinterpret_cast<const TO*>(aux)[o]));
     }
   }
 };
@@ -107,9 +113,9 @@ static int run_generic(const void* A, int64_t sam, int64_t sak, const void* Bm, 
 
 static int check_epi(const Epi& e, int dt, const char* who) {
   MAE_REQUIRE(e.out, "%s: null output", who);
-  MAE_REQUIRE(e.mode >= MAE_EPI_NONE && e.mode <= MAE_EPI_DGELU, "%s: unknown epilogue %d", who, e.mode);
-  MAE_REQUIRE(e.mode != MAE_EPI_GELU || e.out2, "%s: GELU epilogue needs out2", who);
-  MAE_REQUIRE((e.mode != MAE_EPI_RESID && e.mode != MAE_EPI_DGELU) || e.aux, "%s: epilogue needs aux", who);
+  MAE_REQUIRE(e.mode >= MAE_EPI_NONE && e.mode <= MAE_EPI_MUL, "%s: unknown epilogue %d", who, e.mode);
+  MAE_REQUIRE((e.mode != MAE_EPI_GELU && e.mode != MAE_EPI_GELU_GRAD) || e.out2, "%s: GELU epilogue needs out2", who);
+  MAE_REQUIRE((e.mode != MAE_EPI_RESID && e.mode != MAE_EPI_DGELU && e.mode != MAE_EPI_MUL) || e.aux, "%s: epilogue needs aux", who);
   MAE_REQUIRE(e.mode != MAE_EPI_RESID || e.out_dt == MAE_F32, "%s: RESID epilogue writes fp32", who);
   MAE_REQUIRE(dt == MAE_F32 || dt == MAE_BF16, "%s: bad dtype %d", who, dt);
   MAE_REQUIRE(!(dt == MAE_F32 && e.out_dt == MAE_BF16), "%s: fp32 operands with bf16 output unsupported", who);
@@ -136,7 +142,7 @@ int launch_linear_fwd(const void* A, const void* W, int64_t M, int N, int K, int
 int launch_linear_dgrad(const void* dY, const void* W, int64_t M, int N, int K, int dt, const Epi& e, hipStream_t s) {
   MAE_REQUIRE(dY && W && M > 0 && N > 0 && K > 0, "linear_dgrad: bad arguments");
   MAE_TRY(check_epi(e, dt, "linear_dgrad"));
-  MAE_REQUIRE(e.mode == MAE_EPI_NONE || e.mode == MAE_EPI_DGELU, "linear_dgrad: epilogue must be NONE or DGELU");
+  MAE_REQUIRE(e.mode == MAE_EPI_NONE || e.mode == MAE_EPI_DGELU || e.mode == MAE_EPI_MUL, "linear_dgrad: epilogue must be NONE, DGELU or MUL");
   // dX[m][k] = sum_n dY[m][n] W[n][k]: reduction length N, output width K
   if (dt == MAE_BF16) {
     if (e.out_dt == MAE_BF16) return run_generic<bf16, bf16>(dY, N, 1, W, K, 1, M, K, N, e, s);

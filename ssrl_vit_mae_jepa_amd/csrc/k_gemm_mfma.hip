@@ -16,25 +16,6 @@
 
 namespace mae {
 
-// erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): one v_exp + one v_rcp; outputs are rounded to bf16 anyway.
-__device__ __forceinline__ void erf_parts(float x, float& erf_abs, float& e) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  e = __expf(-z * z);  // = exp(-x^2/2)
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  erf_abs = 1.0f - poly * e;
-}
-__device__ __forceinline__ float gelu_fast(float x) {
-  float ea, e;
-  erf_parts(x, ea, e);
-  return 0.5f * x * (1.0f + copysignf(ea, x));
-}
-__device__ __forceinline__ float gelu_grad_fast(float x) {
-  float ea, e;
-  erf_parts(x, ea, e);
-  return 0.5f * (1.0f + copysignf(ea, x)) + x * 0.39894228040143267794f * e;
-}
-
 __device__ __forceinline__ void store8(float* p, const f32x4& a, const f32x4& b) { store4(p, a); store4(p + 4, b); }
 __device__ __forceinline__ void store8(bf16* p, const f32x4& a, const f32x4& b) {
   *reinterpret_cast<bf16x8*>(p) = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
@@ -177,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
         v0 += load4(reinterpret_cast<const float*>(ep.aux) + o);
         v1 += load4(reinterpret_cast<const float*>(ep.aux) + o + 4);
         store8(reinterpret_cast<TO*>(ep.out) + o, v0, v1);
-      } else {
+      } else if (MODE == MAE_EPI_DGELU) {
         f32x4 p0, p1;
         load8(reinterpret_cast<const TO*>(ep.aux) + o, p0, p1);
 #pragma unroll
@@ -186,6 +167,19 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
           v1[r] *= gelu_grad_fast(p1[r]);
         }
         store8(reinterpret_cast<TO*>(ep.out) + o, v0, v1);
+      } else if (MODE == MAE_EPI_GELU_GRAD) {
+        f32x4 a0, a1, g0, g1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          { float _a, _g; gelu_fast_pair(to_f(from_f<TO>(v0[r])), _a, _g); a0[r] = _a; g0[r] = _g; }
+          { float _a, _g; gelu_fast_pair(to_f(from_f<TO>(v1[r])), _a, _g); a1[r] = _a; g1[r] = _g; }
+        }
+        store8(reinterpret_cast<TO*>(ep.out) + o, g0, g1);
+        store8(reinterpret_cast<TO*>(ep.out2) + o, a0, a1);
+      } else {  // MAE_EPI_MUL
+        f32x4 p0, p1;
+        load8(reinterpret_cast<const TO*>(ep.aux) + o, p0, p1);
+        store8(reinterpret_cast<TO*>(ep.out) + o, v0 * p0, v1 * p1);
       }
     }
   }
@@ -222,6 +216,8 @@ int mfma_linear_fwd(const bf16* A, const bf16* W, int64_t M, int N, int K, const
     case MAE_EPI_GELU: return f32out ? launch_nt_ni<MAE_EPI_GELU, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_GELU, bf16>(A, W, M, N, K, e, s);
     case MAE_EPI_RESID: return f32out ? launch_nt_ni<MAE_EPI_RESID, float>(A, W, M, N, K, e, s) : MFMA_UNSUPPORTED;
     case MAE_EPI_DGELU: return f32out ? launch_nt_ni<MAE_EPI_DGELU, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_DGELU, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_GELU_GRAD: return f32out ? launch_nt_ni<MAE_EPI_GELU_GRAD, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_GELU_GRAD, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_MUL: return f32out ? launch_nt_ni<MAE_EPI_MUL, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_MUL, bf16>(A, W, M, N, K, e, s);
     default: return MFMA_UNSUPPORTED;
   }
 }

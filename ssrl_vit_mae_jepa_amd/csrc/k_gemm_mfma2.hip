@@ -16,6 +16,7 @@
 //     epilogue needs no ordinary global load (hipcc drains the DMA queue with vmcnt(0) before using one).
 //   * blocks are XCD-remapped so the 32 CUs of an XCD work on adjacent tiles (shared A panels / W tiles in L2).
 #include "gemm_mfma.h"
+#include <cstdlib>
 
 namespace mae {
 
@@ -35,21 +36,6 @@ struct Geo {  // NI = 16-column MFMA tiles per wave along N (2 waves along N): B
   static constexpr int NBIAS = BN / 64;                            // 256-byte bias DMAs per wave at the first K-step of a tile
 };
 
-__device__ __forceinline__ float gelu_fast2(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  const float e = __expf(-z * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  return 0.5f * x * (1.0f + copysignf(1.0f - poly * e, x));
-}
-
-__device__ __forceinline__ float gelu_grad_fast2(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  const float e = __expf(-z * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  return 0.5f * (1.0f + copysignf(1.0f - poly * e, x)) + x * 0.39894228040143267794f * e;
-}
 __device__ __forceinline__ void ld8(const float* p, f32x4& a, f32x4& b) { a = load4(p); b = load4(p + 4); }
 __device__ __forceinline__ void ld8(const bf16* p, f32x4& a, f32x4& b) {
   const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
@@ -89,7 +75,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
   constexpr int BN = G_::BN, STAGE = G_::STAGE, NSTAGE = G_::NSTAGE, AHEAD = G_::AHEAD, GPW = G_::GPW;
   constexpr int NB = HAS_BIAS ? G_::NBIAS : 0;
   constexpr int STORE8 = sizeof(TO) == 2 ? 1 : 2;                                // store instructions per 8 outputs
-  constexpr int E = 4 * (NI / 2) * STORE8 * (MODE == MAE_EPI_GELU ? 2 : 1);      // epilogue stores per wave (full tile)
+  constexpr int E = 4 * (NI / 2) * STORE8 * ((MODE == MAE_EPI_GELU || MODE == MAE_EPI_GELU_GRAD) ? 2 : 1);      // epilogue stores per wave (full tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,24 +162,27 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (step + AHEAD < nsteps) issue();  // refills the stage every wave finished reading in the previous iteration
-
     const char* a_base = smem + cs * STAGE + (wm * 64 + fr) * 128;
     const char* b_base = smem + cs * STAGE + BM2 * 128 + (wn * (NI * 16) + fr) * 128;
+    // fragments of both 32-deep halves are read up front, the DMA refill is issued between the two read bursts
+    bf16x8 af[2][4], bfr[2][NI];
+    const int sw0 = ((0 + fq) ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int sw = ((ks * 4 + fq) ^ (fr & 7)) << 4;
-      bf16x8 af[4], bfr[NI];
+    for (int mi = 0; mi < 4; ++mi) af[0][mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw0);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) af[mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw);
+    for (int ni = 0; ni < NI; ++ni) bfr[0][ni] = *reinterpret_cast<const bf16x8*>(b_base + ni * 16 * 128 + sw0);
+    if (step + AHEAD < nsteps) issue();  // refills the stage every wave finished reading in the previous iteration
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bfr[ni] = *reinterpret_cast<const bf16x8*>(b_base + ni * 16 * 128 + sw);
+    for (int mi = 0; mi < 4; ++mi) af[1][mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bfr[1][ni] = *reinterpret_cast<const bf16x8*>(b_base + ni * 16 * 128 + sw1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
-    }
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
     cs = cs == NSTAGE - 1 ? 0 : cs + 1;
 
     if (++ck == nk) {
@@ -229,8 +218,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
               for (int r = 0; r < 4; ++r) {
                 v0[r] = to_f(from_f<TO>(v0[r]));
                 v1[r] = to_f(from_f<TO>(v1[r]));
-                a0[r] = gelu_fast2(v0[r]);
-                a1[r] = gelu_fast2(v1[r]);
+                a0[r] = gelu_fast(v0[r]);
+                a1[r] = gelu_fast(v1[r]);
               }
               st8(out + o, v0, v1);
               st8(out2 + o, a0, a1);
@@ -243,10 +232,23 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
               ld8(reinterpret_cast<const TO*>(aux) + o, q0, q1);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                v0[r] *= gelu_grad_fast2(q0[r]);
-                v1[r] *= gelu_grad_fast2(q1[r]);
+                v0[r] *= gelu_grad_fast(q0[r]);
+                v1[r] *= gelu_grad_fast(q1[r]);
               }
               st8(out + o, v0, v1);
+            } else if (MODE == MAE_EPI_GELU_GRAD) {
+              f32x4 a0, a1, g0, g1;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                { float _a, _g; gelu_fast_pair(to_f(from_f<TO>(v0[r])), _a, _g); a0[r] = _a; g0[r] = _g; }
+                { float _a, _g; gelu_fast_pair(to_f(from_f<TO>(v1[r])), _a, _g); a1[r] = _a; g1[r] = _g; }
+              }
+              st8(out + o, g0, g1);
+              st8(out2 + o, a0, a1);
+            } else if (MODE == MAE_EPI_MUL) {
+              f32x4 q0, q1;
+              ld8(reinterpret_cast<const TO*>(aux) + o, q0, q1);
+              st8(out + o, v0 * q0, v1 * q1);
             } else {
               st8(out + o, v0, v1);
             }
@@ -297,6 +299,8 @@ int mfma_linear_fwd_v2(const bf16* A, const bf16* W, int64_t M, int N, int K, co
     case MAE_EPI_GELU: return f32out ? launch_nt2_ni<MAE_EPI_GELU, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_GELU, bf16>(A, W, M, N, K, e, s);
     case MAE_EPI_RESID: return f32out ? launch_nt2_ni<MAE_EPI_RESID, float>(A, W, M, N, K, e, s) : MFMA_UNSUPPORTED;
     case MAE_EPI_DGELU: return f32out ? launch_nt2_ni<MAE_EPI_DGELU, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_DGELU, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_GELU_GRAD: return f32out ? launch_nt2_ni<MAE_EPI_GELU_GRAD, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_GELU_GRAD, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_MUL: return f32out ? launch_nt2_ni<MAE_EPI_MUL, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_MUL, bf16>(A, W, M, N, K, e, s);
     default: return MFMA_UNSUPPORTED;
   }
 }

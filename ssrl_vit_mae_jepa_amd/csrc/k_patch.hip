@@ -88,27 +88,30 @@ int launch_assemble_visible(float* x, const int32_t* tok, const float* cls, cons
   return 0;
 }
 
-// Second stage of every two-stage column reduction: 32 columns per block, 8 row lanes per column, fixed order.
+// Second stage of every two-stage column reduction: 32 columns per block (8 lanes x float4), 32 row lanes, fixed order.
 __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ partial, int G, int C,
                                                            float* __restrict__ out0, float* __restrict__ out1, int split) {
-  __shared__ float red[8][33];
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
-  float acc = 0.f;
+  __shared__ __attribute__((aligned(16))) float red[32][36];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 32 + cl * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (c < C)
-    for (int i = rl; i < G; i += 8) acc += partial[(int64_t)i * C + c];
-  red[rl][cl] = acc;
+    for (int i = rl; i < G; i += 32) acc += load4(partial + (int64_t)i * C + c);
+  store4(&red[rl][cl * 4], acc);
   __syncthreads();
-  if (rl == 0 && c < C) {
-    float v = red[0][cl];
+  if (threadIdx.x < 32) {
+    const int cc = blockIdx.x * 32 + threadIdx.x;
+    if (cc < C) {
+      float v = 0.f;
 #pragma unroll
-    for (int j = 1; j < 8; ++j) v += red[j][cl];
-    if (c < split) out0[c] = v; else out1[c - split] = v;
+      for (int j = 0; j < 32; ++j) v += red[j][threadIdx.x];
+      if (cc < split) out0[cc] = v; else out1[cc - split] = v;
+    }
   }
 }
 
 int launch_sum_partials(const float* partial, int G, int C, float* out0, float* out1, int split, hipStream_t s) {
-  MAE_REQUIRE(partial && out0 && G > 0 && C > 0 && (split >= C || out1), "sum_partials: bad arguments");
+  MAE_REQUIRE(partial && out0 && G > 0 && C > 0 && C % 4 == 0 && (split >= C || out1), "sum_partials: bad arguments (C %% 4 == 0)");
   hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, s, partial, G, C, out0, out1, split);
   MAE_LAUNCH_CHECK();
   return 0;

@@ -150,7 +150,7 @@ LIN_SHAPES = [(70, 144, 192), (72, 432, 144), (300, 576, 144), (145, 192, 768), 
 
 @pytest.mark.parametrize("M,N,K", LIN_SHAPES)
 @pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("epi", ["none", "gelu", "resid", "dgelu", "none_f32out"])
+@pytest.mark.parametrize("epi", ["none", "gelu", "resid", "dgelu", "none_f32out", "gelu_grad", "mul"])
 def test_linear_fwd(dev, M, N, K, dt, epi):
     if dt == F32 and epi == "none_f32out":
         pytest.skip("same as none")
@@ -162,21 +162,28 @@ def test_linear_fwd(dev, M, N, K, dt, epi):
     out = torch.full((M, N), float("nan"), dtype=TDT[odt], device=dev)
     out2 = torch.full((M, N), float("nan"), dtype=TDT[odt], device=dev)
     aux = None
-    mode = {"none": 0, "none_f32out": 0, "gelu": 1, "resid": 2, "dgelu": 3}[epi]
+    mode = {"none": 0, "none_f32out": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5}[epi]
     if epi == "resid":
         aux = torch.randn(M, N, generator=g)
         ref = aux.double() + acc + bias.double()
     elif epi == "dgelu":
         aux = torch.randn(M, N, generator=g).to(TDT[odt])
         ref = (acc + bias.double()) * _gelu_grad(aux.double())
+    elif epi == "mul":
+        aux = torch.randn(M, N, generator=g).to(TDT[odt])
+        ref = (acc + bias.double()) * aux.double()
+    elif epi == "gelu_grad":
+        ref = _gelu_grad((acc + bias.double()).to(TDT[odt]).double())
     else:
         ref = acc + bias.double()
     check(lib.mae_linear_fwd(_ptr(dv(A)), _ptr(dv(W)), _ptr(dv(bias)), M, N, K, dt, mode, odt, _ptr(out),
-                             _ptr(out2) if epi == "gelu" else None, _ptr(dv(aux)) if aux is not None else None, stream(dev)))
+                             _ptr(out2) if epi in ("gelu", "gelu_grad") else None, _ptr(dv(aux)) if aux is not None else None, stream(dev)))
     tol = 2e-5 if odt == F32 and dt == F32 else (1e-5 if odt == F32 else 5e-3)
     assert rel_err(out.float(), ref) < tol
     if epi == "gelu":
         assert rel_err(out2.float(), F.gelu(out.float().cpu().double())) < (1e-5 if odt == F32 else 5e-3)
+    if epi == "gelu_grad":
+        assert rel_err(out2.float(), F.gelu((acc + bias.double()).to(TDT[odt]).double())) < (2e-5 if odt == F32 else 5e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(70, 144, 192), (5000, 432, 144), (4100, 192, 768), (9000, 384, 384), (300, 16, 32), (8200, 1536, 384), (6000, 384, 1536)])

@@ -18,6 +18,8 @@ SHAPES = [  # name, M, N, K, epilogue, out dtype
     ("enc proj fwd", 72000, 384, 384, "none", BF16),
     ("enc fc2 fwd", 72000, 384, 1536, "none", BF16),
     ("enc fc2 dgrad (dgelu)", 72000, 1536, 384, "dgelu", BF16),
+    ("enc fc1 fwd (gelu_grad)", 72000, 1536, 384, "gelu_grad", BF16),
+    ("enc fc2 dgrad (mul)", 72000, 1536, 384, "mul", BF16),
     ("enc qkv dgrad", 72000, 384, 1152, "none", BF16),
     ("enc proj fwd resid", 72000, 384, 384, "resid", F32),
     ("dec qkv fwd", 290000, 576, 192, "none", BF16),
@@ -25,8 +27,13 @@ SHAPES = [  # name, M, N, K, epilogue, out dtype
     ("dec fc2 fwd", 290000, 192, 768, "none", BF16),
     ("patch embed", 72000, 384, 192, "none", F32),
     ("pred head", 218000, 192, 192, "none", F32),
+    # cache-resident probes (operands + output fit the 256 MiB Infinity Cache after the first round)
+    ("probe qkv M=32768", 32768, 1152, 384, "none", BF16),
+    ("probe fc2 M=32768", 32768, 384, 1536, "none", BF16),
+    ("probe fc1 none", 72000, 1536, 384, "none", BF16),
+    ("probe K=4096", 32768, 1152, 4096, "none", BF16),
 ]
-MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3}
+MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5}
 
 
 def main():
@@ -47,7 +54,7 @@ def main():
         aux = None
         if epi == "resid":
             aux = torch.rand(M, N, device=dev, generator=g)
-        elif epi == "dgelu":
+        elif epi in ("dgelu", "mul"):
             aux = (torch.rand(M, N, device=dev, generator=g) * 4 - 2).to(TDT[odt])
         outs, times = {}, {v: [] for v in variants}
         for v in variants:
@@ -56,7 +63,7 @@ def main():
         def run(v):
             os.environ["MAE_GEMM_NT"] = v
             o, o2 = outs[v]
-            check(lib.mae_linear_fwd(_ptr(A), _ptr(W), _ptr(bias), M, N, K, BF16, MODE[epi], odt, _ptr(o), _ptr(o2) if epi == "gelu" else None,
+            check(lib.mae_linear_fwd(_ptr(A), _ptr(W), _ptr(bias), M, N, K, BF16, MODE[epi], odt, _ptr(o), _ptr(o2) if epi in ("gelu", "gelu_grad") else None,
                                      _ptr(aux) if aux is not None else None, stream(dev)))
         for v in variants:
             run(v)
@@ -67,13 +74,13 @@ def main():
                 e0.record(); run(v); e1.record(); torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) * 1e3)
         osz = 4 if odt == F32 else 2
-        nbytes = M * K * 2 + N * K * 2 + M * N * osz * (2 if epi == "gelu" else 1) + (M * N * (4 if epi == "resid" else osz) if aux is not None else 0)
+        nbytes = M * K * 2 + N * K * 2 + M * N * osz * (2 if epi in ("gelu", "gelu_grad") else 1) + (M * N * (4 if epi == "resid" else osz) if aux is not None else 0)
         line = f"{name:24s} M={M} N={N} K={K}"
         for v in variants:
             t = sorted(times[v])[len(times[v]) // 2]
             line += f" | {v}: {t:7.1f} us {2 * M * N * K / t / 1e6:6.0f} TF/s {nbytes / t / 1e3:5.0f} GB/s"
         if len(variants) == 2:
-            same = torch.equal(outs[variants[0]][0], outs[variants[1]][0]) and (epi != "gelu" or torch.equal(outs[variants[0]][1], outs[variants[1]][1]))
+            same = torch.equal(outs[variants[0]][0], outs[variants[1]][0]) and (epi not in ("gelu", "gelu_grad") or torch.equal(outs[variants[0]][1], outs[variants[1]][1]))
             line += f" | bitwise-equal={same}"
         print(line, flush=True)
 
