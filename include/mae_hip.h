@@ -162,6 +162,11 @@ int         mae_engine_timers_reset(mae_engine_t* e);
  * mean/rstd: (rows) fp32 saved for backward. */
 int mae_layernorm_fwd(const float* x, const int32_t* row_map, const float* gamma, const float* beta, float eps,
                       int64_t rows, int32_t dim, int32_t y_dtype, void* y, float* mean, float* rstd, void* stream);
+/* Same with the residual add fused in: v = x[row] + branch[row] (branch in y_dtype); x_out[row] = v (fp32); y = LN(v).
+ * This is `x = x + attn(...)` / `x = x + mlp(...)` of timm Block followed by the next norm. */
+int mae_add_layernorm_fwd(const float* x, const void* branch, float* x_out, const int32_t* row_map, const float* gamma,
+                          const float* beta, float eps, int64_t rows, int32_t dim, int32_t y_dtype, void* y, float* mean,
+                          float* rstd, void* stream);
 /* Backward: dx_io[row] = (accumulate ? dx_io[row] : 0) + dLN/dx ; dx_copy (dtype, may be NULL) gets the
  * same value in the activation dtype; dgamma/dbeta (dim) written.  partial: >= 2*1024*dim floats. */
 int mae_layernorm_bwd(const void* dy, int32_t dy_dtype, const float* x, const int32_t* row_map, const float* gamma,

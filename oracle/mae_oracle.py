@@ -275,7 +275,8 @@ def _attention(x, p, pfx, heads, bf16):
     att = (q * hd ** -0.5) @ k.transpose(-2, -1)
     att = att.softmax(dim=-1)
     o = (_r(att, bf16) @ v).transpose(1, 2).reshape(B, T, C)
-    return _linear(_r(o, bf16), p[f"{pfx}.attn.proj.weight"], p[f"{pfx}.attn.proj.bias"], bf16)
+    # under bf16-mixed autocast the Linear output is bf16 before it is added to the fp32 residual stream
+    return _r(_linear(_r(o, bf16), p[f"{pfx}.attn.proj.weight"], p[f"{pfx}.attn.proj.bias"], bf16), bf16)
 
 
 def _block(x, p, pfx, heads, bf16):
@@ -285,7 +286,7 @@ def _block(x, p, pfx, heads, bf16):
     h = F.layer_norm(x, (C,), p[f"{pfx}.norm2.weight"], p[f"{pfx}.norm2.bias"], LN_EPS)
     h = _linear(h, p[f"{pfx}.mlp.fc1.weight"], p[f"{pfx}.mlp.fc1.bias"], bf16)
     h = F.gelu(_r(h, bf16))  # nn.GELU() default = exact erf
-    h = _linear(h, p[f"{pfx}.mlp.fc2.weight"], p[f"{pfx}.mlp.fc2.bias"], bf16)
+    h = _r(_linear(h, p[f"{pfx}.mlp.fc2.weight"], p[f"{pfx}.mlp.fc2.bias"], bf16), bf16)
     return x + h
 
 
@@ -317,7 +318,7 @@ def forward_decoder(p, cfg: MAEConfig, x_encoded, idx_keep, idx_mask, bf16=False
     """src/models/mae.py:57-75."""
     B = x_encoded.shape[0]
     Dd, L = cfg.decoder_embed_dim, cfg.sequence_length
-    x_decode = _linear(x_encoded, p["decoder.decoder_embed.weight"], p["decoder.decoder_embed.bias"], bf16)
+    x_decode = _r(_linear(x_encoded, p["decoder.decoder_embed.weight"], p["decoder.decoder_embed.bias"], bf16), bf16)
     x_masked = p["decoder.mask_token"].repeat(B, L, 1)
     x_masked = torch.scatter(x_masked, 1, idx_keep.unsqueeze(-1).expand(-1, -1, Dd), x_decode.type_as(x_masked))
     x = x_masked + p["decoder.decoder_pos_embed"]

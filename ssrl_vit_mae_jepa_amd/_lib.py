@@ -71,6 +71,7 @@ SIGNATURES = {
     "mae_engine_timer_read": (C.c_int, [_vp, _i32, _pp(C.c_double), _pp(_i64), _pp(C.c_double), _pp(C.c_double)]),
     "mae_engine_timers_reset": (C.c_int, [_vp]),
     "mae_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mae_add_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mae_layernorm_bwd": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mae_linear_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mae_linear_wgrad_scratch_bytes": (_i64, [_i64, _i32, _i32]),

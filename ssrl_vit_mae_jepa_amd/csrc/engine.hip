@@ -116,6 +116,7 @@ struct Plan {
   std::vector<LayerBufs> enc, dec;
   int64_t enc_norm, enc_mean, enc_rstd, xdec, dec_norm, dec_mean, dec_rstd, pred;
   // backward scratch
+  int64_t branch_a, branch_b;  // bf16/fp32 outputs of the attention / MLP branches (added by the next LayerNorm kernel)
   int64_t dpred, d_decn, dres, dres_c, d_ln, d_att, d_qkv, d_hidden, d_xdec, dtok;
   int64_t ln_partial, split_partial, wgrad_scratch, loss_scratch;
   int64_t total;
@@ -159,6 +160,8 @@ static Plan make_plan(const mae_engine* e, int B, int k) {
   pl.pred = take(std::max<int64_t>(pl.Mp, 1) * e->P * 4);
   // backward scratch, shared by the decoder and encoder sweeps
   const int64_t R = std::max(pl.Me * e->D, pl.Md * e->Dd);
+  pl.branch_a = take(R * as);
+  pl.branch_b = take(R * as);
   pl.dpred = take(std::max<int64_t>(pl.Mp, 1) * e->P * as);
   pl.d_decn = take(std::max<int64_t>(pl.Mp, 1) * e->Dd * as);
   pl.dres = take(R * 4);
@@ -263,18 +266,25 @@ static int wgrad(const Ctx& c, const Plan& pl, const void* dY, const void* A, in
   return 0;
 }
 
-static int block_forward(const Ctx& c, const BlockRefs& r, const LayerBufs& b, int64_t M, int d, int heads, int Bn, int T, int64_t x_in,
-                         int64_t x_out) {
+// One transformer block.  The residual adds are done by the LayerNorm kernels: LN1 first forms this block's input
+// x_in = x_prev + prev_branch (the previous block's MLP output; none for the first block), LN2 forms x_mid = x_in + proj(att).
+// The block's own MLP output is left in pl.branch_b for whoever normalises next.
+static int block_forward(const Ctx& c, const Plan& pl, const BlockRefs& r, const LayerBufs& b, int64_t M, int d, int heads, int Bn, int T,
+                         int64_t x_prev, bool add_prev, int64_t x_in) {
   mae_engine* e = c.e; hipStream_t s = c.s;
   const int hd = d / heads, hid = e->mlp * d;
   const float eps = 1e-6f;
-  RUN(TK_LN_FWD, 0, M * d * (4 + c.as), launch_layernorm_fwd(c.buf<float>(x_in), nullptr, c.P(r.ln1_w), c.P(r.ln1_b), eps, M, d, c.act, c.buf<>(b.ln1), c.buf<float>(b.mean1), c.buf<float>(b.rstd1), s));
+  if (add_prev) {
+    RUN(TK_LN_FWD, 0, M * d * (8 + 2 * c.as), launch_layernorm_fwd(c.buf<float>(x_prev), c.buf<>(pl.branch_b), c.buf<float>(x_in), nullptr, c.P(r.ln1_w), c.P(r.ln1_b), eps, M, d, c.act, c.buf<>(b.ln1), c.buf<float>(b.mean1), c.buf<float>(b.rstd1), s));
+  } else {
+    RUN(TK_LN_FWD, 0, M * d * (4 + c.as), launch_layernorm_fwd(c.buf<float>(x_in), nullptr, nullptr, nullptr, c.P(r.ln1_w), c.P(r.ln1_b), eps, M, d, c.act, c.buf<>(b.ln1), c.buf<float>(b.mean1), c.buf<float>(b.rstd1), s));
+  }
   MAE_TRY(linear(c, c.buf<>(b.ln1), r.qkv_w, r.qkv_b, M, 3 * d, d, MAE_EPI_NONE, c.act, c.buf<>(b.qkv), nullptr, nullptr));
   RUN(TK_ATTN_FWD, 4.0 * Bn * heads * (double)T * T * hd, M * 4 * d * c.as, launch_attention_fwd(c.buf<>(b.qkv), Bn, T, heads, hd, c.act, c.buf<>(b.att), c.buf<float>(b.lse), s));
-  MAE_TRY(linear(c, c.buf<>(b.att), r.proj_w, r.proj_b, M, d, d, MAE_EPI_RESID, MAE_F32, c.buf<>(b.x_mid), nullptr, c.buf<>(x_in)));
-  RUN(TK_LN_FWD, 0, M * d * (4 + c.as), launch_layernorm_fwd(c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.P(r.ln2_b), eps, M, d, c.act, c.buf<>(b.ln2), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), s));
+  MAE_TRY(linear(c, c.buf<>(b.att), r.proj_w, r.proj_b, M, d, d, MAE_EPI_NONE, c.act, c.buf<>(pl.branch_a), nullptr, nullptr));
+  RUN(TK_LN_FWD, 0, M * d * (8 + 2 * c.as), launch_layernorm_fwd(c.buf<float>(x_in), c.buf<>(pl.branch_a), c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.P(r.ln2_b), eps, M, d, c.act, c.buf<>(b.ln2), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), s));
   MAE_TRY(linear(c, c.buf<>(b.ln2), r.fc1_w, r.fc1_b, M, hid, d, MAE_EPI_GELU_GRAD, c.act, c.buf<>(b.fc1_pre), c.buf<>(b.fc1_act), nullptr));  // fc1_pre holds gelu'(pre)
-  MAE_TRY(linear(c, c.buf<>(b.fc1_act), r.fc2_w, r.fc2_b, M, d, hid, MAE_EPI_RESID, MAE_F32, c.buf<>(x_out), nullptr, c.buf<>(b.x_mid)));
+  MAE_TRY(linear(c, c.buf<>(b.fc1_act), r.fc2_w, r.fc2_b, M, d, hid, MAE_EPI_NONE, c.act, c.buf<>(pl.branch_b), nullptr, nullptr));
   return 0;
 }
 
@@ -322,11 +332,11 @@ static int forward_encoder_impl(const Ctx& c, const Plan& pl, const float* image
   MAE_TRY(linear(c, c.buf<>(pl.patchA), e->i_patch_w, e->i_patch_b, pl.Me, e->D, e->P, MAE_EPI_NONE, MAE_F32, c.buf<>(pl.enc_x[0]), nullptr, nullptr));
   RUN(TK_DATA, 0, pl.Me * e->D * 12, launch_assemble_visible(c.buf<float>(pl.enc_x[0]), keep32, c.P(e->i_cls), c.P(e->i_pos), pl.Me, e->D, s));
   for (int i = 0; i < e->depth; ++i)
-    MAE_TRY(block_forward(c, e->enc[i], pl.enc[i], pl.Me, e->D, e->H, pl.B, pl.k, pl.enc_x[i], pl.enc_x[i + 1]));
-  RUN(TK_LN_FWD, 0, pl.Me * e->D * (4 + c.as), launch_layernorm_fwd(c.buf<float>(pl.enc_x[e->depth]), nullptr, c.P(e->i_norm_w), c.P(e->i_norm_b), 1e-6f, pl.Me, e->D, c.act, c.buf<>(pl.enc_norm), c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), s));
+    MAE_TRY(block_forward(c, pl, e->enc[i], pl.enc[i], pl.Me, e->D, e->H, pl.B, pl.k, i ? pl.enc[i - 1].x_mid : 0, i > 0, pl.enc_x[i]));
+  RUN(TK_LN_FWD, 0, pl.Me * e->D * (8 + 2 * c.as), launch_layernorm_fwd(c.buf<float>(pl.enc[e->depth - 1].x_mid), c.buf<>(pl.branch_b), c.buf<float>(pl.enc_x[e->depth]), nullptr, c.P(e->i_norm_w), c.P(e->i_norm_b), 1e-6f, pl.Me, e->D, c.act, c.buf<>(pl.enc_norm), c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), s));
   if (x_encoded_out) {
     if (c.act == MAE_F32) MAE_HIP(hipMemcpyAsync(x_encoded_out, c.buf<>(pl.enc_norm), (size_t)pl.Me * e->D * 4, hipMemcpyDeviceToDevice, s));
-    else RUN(TK_LN_FWD, 0, pl.Me * e->D * 8, launch_layernorm_fwd(c.buf<float>(pl.enc_x[e->depth]), nullptr, c.P(e->i_norm_w), c.P(e->i_norm_b), 1e-6f, pl.Me, e->D, MAE_F32, x_encoded_out, c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), s));
+    else RUN(TK_LN_FWD, 0, pl.Me * e->D * 8, launch_layernorm_fwd(c.buf<float>(pl.enc_x[e->depth]), nullptr, nullptr, nullptr, c.P(e->i_norm_w), c.P(e->i_norm_b), 1e-6f, pl.Me, e->D, MAE_F32, x_encoded_out, c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), s));
   }
   return 0;
 }
@@ -340,8 +350,9 @@ static int forward_decoder_impl(const Ctx& c, const Plan& pl, float* x_pred_out)
   MAE_TRY(linear(c, c.buf<>(pl.enc_norm), e->i_de_w, e->i_de_b, pl.Me, e->Dd, e->D, MAE_EPI_NONE, c.act, c.buf<>(pl.xdec), nullptr, nullptr));
   RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_decoder_assemble(c.buf<>(pl.xdec), c.act, c.buf<int32_t>(pl.inv), c.P(e->i_dec_mask), c.P(e->i_dec_pos), pl.B, pl.k, e->L, e->Dd, c.buf<float>(pl.dec_x[0]), s));
   for (int i = 0; i < e->dd; ++i)
-    MAE_TRY(block_forward(c, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.B, e->L, pl.dec_x[i], pl.dec_x[i + 1]));
-  RUN(TK_LN_FWD, 0, pl.Mp * e->Dd * (4 + c.as), launch_layernorm_fwd(c.buf<float>(pl.dec_x[e->dd]), c.buf<int32_t>(pl.pred_rows), c.P(e->i_dn_w), c.P(e->i_dn_b), 1e-6f, pl.Mp, e->Dd, c.act, c.buf<>(pl.dec_norm), c.buf<float>(pl.dec_mean), c.buf<float>(pl.dec_rstd), s));
+    MAE_TRY(block_forward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.B, e->L, i ? pl.dec[i - 1].x_mid : 0, i > 0, pl.dec_x[i]));
+  // decoder_norm on the masked rows only; the residual add of the last MLP branch is done for exactly those rows
+  RUN(TK_LN_FWD, 0, pl.Mp * e->Dd * (8 + 2 * c.as), launch_layernorm_fwd(c.buf<float>(pl.dec[e->dd - 1].x_mid), c.buf<>(pl.branch_b), c.buf<float>(pl.dec_x[e->dd]), c.buf<int32_t>(pl.pred_rows), c.P(e->i_dn_w), c.P(e->i_dn_b), 1e-6f, pl.Mp, e->Dd, c.act, c.buf<>(pl.dec_norm), c.buf<float>(pl.dec_mean), c.buf<float>(pl.dec_rstd), s));
   MAE_TRY(linear(c, c.buf<>(pl.dec_norm), e->i_pred_w, e->i_pred_b, pl.Mp, e->P, e->Dd, MAE_EPI_NONE, MAE_F32, x_pred_out ? (void*)x_pred_out : c.buf<>(pl.pred), nullptr, nullptr));
   return 0;
 }

@@ -37,6 +37,23 @@ __device__ __forceinline__ void stage_image(char* s, const bf16* g, int64_t gs, 
   }
 }
 
+// Same image filled by LDS-DMA (global_load_lds_dwordx4): every 16-byte slot of the padded image is one lane of one
+// DMA, all of a wave's DMAs are in flight together (the register-staged loop above serialises ~3 global round trips
+// per image).  Rows past T and the pad chunks read clamped (valid, finite) data: every use of them is multiplied by
+// an exactly-zero probability, so they only have to be finite.  img_bytes is a multiple of 1 KiB.
+template <int HD>
+__device__ __forceinline__ void stage_image_dma(char* s, int img_bytes, const bf16* g, int64_t gs, int T, int wave, int nwaves, int lane) {
+  constexpr int SPR = AT<HD>::RS / 16;  // 16-byte slots per padded row
+  for (int blk = wave; blk * 1024 < img_bytes; blk += nwaves) {
+    const int slot = blk * 64 + lane;
+    int row = slot / SPR, c = slot - row * SPR;
+    row = row < T ? row : T - 1;
+    c = c < AT<HD>::CPR ? c : AT<HD>::CPR - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + row * gs + c * 8),
+                                     (__attribute__((address_space(3))) void*)(s + blk * 1024), 16, 0, 0);
+  }
+}
+
 // operand indexed by token row (row0 + lane&15), elements hd = ks*32 + 8*(lane>>4) .. +7
 template <int HD>
 __device__ __forceinline__ bf16x8 rowfrag(const char* s, int row0, int ks, int lane) {
@@ -72,17 +89,20 @@ template <int HD>
 __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
                                                             bf16* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
-  char* sK = sQ + Tp * AT<HD>::RS;
-  char* sV = sK + Tp * AT<HD>::RS;
+  char* sK = sQ + img;
+  char* sV = sK + img;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int64_t gs = 3ll * H * HD;
   const bf16* base = qkv + (int64_t)b * T * gs + h * HD;
-  stage_image<HD>(sQ, base, gs, T, Tp);
-  stage_image<HD>(sK, base + (int64_t)H * HD, gs, T, Tp);
-  stage_image<HD>(sV, base + 2ll * H * HD, gs, T, Tp);
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane);
+  stage_image_dma<HD>(sK, img, base + (int64_t)H * HD, gs, T, wave, nwaves, lane);
+  stage_image_dma<HD>(sV, img, base + 2ll * H * HD, gs, T, wave, nwaves, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int g = lane >> 4, i = lane & 15;
   const float sl2 = scale * kLog2e;
   const int nq = (T + 15) >> 4, nchunks = Tp >> 5;
@@ -146,11 +166,12 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
                                                             const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
                                                             int Tp, int H, float scale, bf16* __restrict__ d_qkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
-  char* sK = sQ + Tp * AT<HD>::RS;
-  char* sV = sK + Tp * AT<HD>::RS;
-  char* sdO = sV + Tp * AT<HD>::RS;
-  float* sLse = reinterpret_cast<float*>(sdO + Tp * AT<HD>::RS);  // pre-multiplied by log2(e); 1e30 on padded rows
+  char* sK = sQ + img;
+  char* sV = sK + img;
+  char* sdO = sV + img;
+  float* sLse = reinterpret_cast<float*>(sdO + img);  // pre-multiplied by log2(e); 1e30 on padded rows
   float* sD = sLse + Tp;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int64_t gs = 3ll * H * HD, os = (int64_t)H * HD;
@@ -158,27 +179,37 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   const bf16* obase = out + (int64_t)b * T * os + h * HD;
   const bf16* dobase = d_out + (int64_t)b * T * os + h * HD;
   bf16* dbase = d_qkv + (int64_t)b * T * gs + h * HD;
-  stage_image<HD>(sQ, base, gs, T, Tp);
-  stage_image<HD>(sK, base + os, gs, T, Tp);
-  stage_image<HD>(sV, base + 2 * os, gs, T, Tp);
-  stage_image<HD>(sdO, dobase, os, T, Tp);
-  for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
-    float D = 0.f, l = 1e30f;
-    if (t < T) {
-#pragma unroll
-      for (int cc = 0; cc < AT<HD>::CPR; ++cc) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(dobase + t * os + cc * 8);
+  const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane);
+  stage_image_dma<HD>(sK, img, base + os, gs, T, wave, nwaves, lane);
+  stage_image_dma<HD>(sV, img, base + 2 * os, gs, T, wave, nwaves, lane);
+  stage_image_dma<HD>(sdO, img, dobase, os, T, wave, nwaves, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // D_t = dO_t . O_t with CPR lanes per row (dO chunk from the staged image, O chunk from global), shuffle-reduced
+  {
+    constexpr int CPR = AT<HD>::CPR;
+    const int total = Tp * CPR;
+    for (int base = 0; base < total; base += blockDim.x) {
+      const int idx = base + threadIdx.x;
+      const int t = idx / CPR, cc = idx - t * CPR;
+      float D = 0.f;
+      if (idx < total && t < T) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sdO + t * AT<HD>::RS + cc * 16);
         const bf16x8 o = *reinterpret_cast<const bf16x8*>(obase + t * os + cc * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) D = fmaf((float)a[e], (float)o[e], D);
       }
-      l = lse[((int64_t)b * H + h) * T + t] * kLog2e;
+#pragma unroll
+      for (int off = CPR / 2; off > 0; off >>= 1) D += __shfl_xor(D, off, 64);
+      if (idx < total && cc == 0) {
+        sD[t] = D;
+        sLse[t] = t < T ? lse[((int64_t)b * H + h) * T + t] * kLog2e : 1e30f;
+      }
     }
-    sLse[t] = l;
-    sD[t] = D;
   }
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int g = lane >> 4, i = lane & 15;
   const float sl2 = scale * kLog2e;
   const int nt16 = (T + 15) >> 4, nchunks = Tp >> 5;
@@ -286,7 +317,7 @@ static bool attn_supported(int T, int H, int hd) {
 int mfma_attention_fwd(const bf16* qkv, int B, int T, int H, int hd, bf16* out, float* lse, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return MFMA_UNSUPPORTED;
   const int Tp = (int)round_up(T, 32);
-  const size_t lds = (size_t)3 * Tp * (hd * 2 + 32);
+  const size_t lds = (size_t)3 * round_up((int64_t)Tp * (hd * 2 + 32), 1024);
   if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
   const float scale = 1.0f / sqrtf((float)hd);
   const dim3 grid((unsigned)B * H), block(64 * attn_waves(T));
@@ -305,7 +336,7 @@ int mfma_attention_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, cons
                        bf16* d_qkv, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)d_qkv) & 15)) return MFMA_UNSUPPORTED;
   const int Tp = (int)round_up(T, 32);
-  const size_t lds = (size_t)4 * Tp * (hd * 2 + 32) + (size_t)2 * Tp * 4;
+  const size_t lds = (size_t)4 * round_up((int64_t)Tp * (hd * 2 + 32), 1024) + (size_t)2 * Tp * 4;
   if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
   const float scale = 1.0f / sqrtf((float)hd);
   const dim3 grid((unsigned)B * H), block(64 * attn_waves(T));

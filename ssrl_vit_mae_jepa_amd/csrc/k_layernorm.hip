@@ -7,8 +7,11 @@
 namespace mae {
 
 // NV = float4 vectors per lane: covers dim <= 256*NV
-template <class T, int NV>
-__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ row_map,
+// ADD: the LayerNorm input is x + branch (the residual add of the preceding attention / MLP branch, whose GEMM then
+// keeps the plain bf16 epilogue); the sum is written to x_out as the new fp32 residual stream.
+template <class T, int NV, bool ADD>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const T* __restrict__ branch,
+                                                            float* __restrict__ x_out, const int32_t* __restrict__ row_map,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float eps, int64_t rows, int dim, T* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out) {
@@ -25,6 +28,10 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
       const int c = lane + 64 * i;
       if (c < D4) {
         v[i] = load4(px + c * 4);
+        if (ADD) {
+          v[i] += load4(branch + src * dim + c * 4);
+          store4(x_out + src * dim + c * 4, v[i]);
+        }
         sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
       } else {
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -58,15 +65,18 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
   }
 }
 
-int launch_layernorm_fwd(const float* x, const int32_t* row_map, const float* gamma, const float* beta, float eps,
-                         int64_t rows, int dim, int y_dt, void* y, float* mean, float* rstd, hipStream_t s) {
+int launch_layernorm_fwd(const float* x, const void* branch, float* x_out, const int32_t* row_map, const float* gamma,
+                         const float* beta, float eps, int64_t rows, int dim, int y_dt, void* y, float* mean, float* rstd,
+                         hipStream_t s) {
   MAE_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0, "layernorm_fwd: null buffer");
+  MAE_REQUIRE(!branch || x_out, "layernorm_fwd: the fused residual add needs x_out");
   MAE_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= 1024, "layernorm: dim %d must be a multiple of 4 in [4, 1024]", dim);
   const int nv = (int)cdiv(dim / 4, 64);
   const int grid = (int)std::min<int64_t>(cdiv(rows, 4), 256 * 32);
-#define LN(T, NV) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV>), dim3(grid), dim3(256), 0, s, x, row_map, gamma, beta, eps, rows, dim, (T*)y, mean, rstd)
-#define LN_NV(T) switch (nv) { case 1: LN(T, 1); break; case 2: LN(T, 2); break; case 3: LN(T, 3); break; default: LN(T, 4); }
-  if (y_dt == MAE_BF16) { LN_NV(bf16) } else { LN_NV(float) }
+#define LN(T, NV, ADD) hipLaunchKernelGGL((layernorm_fwd_kernel<T, NV, ADD>), dim3(grid), dim3(256), 0, s, x, (const T*)branch, x_out, row_map, gamma, beta, eps, rows, dim, (T*)y, mean, rstd)
+#define LN_NV(T, ADD) switch (nv) { case 1: LN(T, 1, ADD); break; case 2: LN(T, 2, ADD); break; case 3: LN(T, 3, ADD); break; default: LN(T, 4, ADD); }
+  if (y_dt == MAE_BF16) { if (branch) { LN_NV(bf16, true) } else { LN_NV(bf16, false) } }
+  else { if (branch) { LN_NV(float, true) } else { LN_NV(float, false) } }
 #undef LN_NV
 #undef LN
   MAE_LAUNCH_CHECK();
@@ -166,7 +176,14 @@ int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_
 extern "C" int mae_layernorm_fwd(const float* x, const int32_t* row_map, const float* gamma, const float* beta, float eps,
                                  int64_t rows, int32_t dim, int32_t y_dtype, void* y, float* mean, float* rstd,
                                  void* stream) {
-  return mae::launch_layernorm_fwd(x, row_map, gamma, beta, eps, rows, dim, y_dtype, y, mean, rstd, (hipStream_t)stream);
+  return mae::launch_layernorm_fwd(x, nullptr, nullptr, row_map, gamma, beta, eps, rows, dim, y_dtype, y, mean, rstd, (hipStream_t)stream);
+}
+
+extern "C" int mae_add_layernorm_fwd(const float* x, const void* branch, float* x_out, const int32_t* row_map, const float* gamma,
+                                     const float* beta, float eps, int64_t rows, int32_t dim, int32_t y_dtype, void* y, float* mean,
+                                     float* rstd, void* stream) {
+  MAE_REQUIRE(branch && x_out, "mae_add_layernorm_fwd: null branch/x_out");
+  return mae::launch_layernorm_fwd(x, branch, x_out, row_map, gamma, beta, eps, rows, dim, y_dtype, y, mean, rstd, (hipStream_t)stream);
 }
 
 extern "C" int mae_layernorm_bwd(const void* dy, int32_t dy_dtype, const float* x, const int32_t* row_map,

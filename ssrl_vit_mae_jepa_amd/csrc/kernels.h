@@ -57,8 +57,10 @@ int launch_f32_to_bf16(const float* src, bf16* dst, int64_t n, hipStream_t s);
 int launch_transpose_to_bf16(const float* src, bf16* dst, int rows, int cols, hipStream_t s);
 
 // ---- k_layernorm.hip --------------------------------------------------------------------------------
-int launch_layernorm_fwd(const float* x, const int32_t* row_map, const float* gamma, const float* beta, float eps,
-                         int64_t rows, int dim, int y_dt, void* y, float* mean, float* rstd, hipStream_t s);
+// y = LN(x [+ branch]); with a branch (dtype y_dt) the sum is also written to x_out (fp32): the fused residual add
+int launch_layernorm_fwd(const float* x, const void* branch, float* x_out, const int32_t* row_map, const float* gamma,
+                         const float* beta, float eps, int64_t rows, int dim, int y_dt, void* y, float* mean, float* rstd,
+                         hipStream_t s);
 int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_t* row_map, const float* gamma,
                          const float* mean, const float* rstd, int64_t rows, int dim, int accumulate, float* dx_io,
                          void* dx_copy, float* dgamma, float* dbeta, float* partial, hipStream_t s);

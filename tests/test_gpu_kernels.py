@@ -139,6 +139,28 @@ def test_layernorm_row_map(dev):
     assert rel_err(dx, xr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_add_layernorm_fwd(dev, dt):
+    g = G(11)
+    rows, dim, n = 40, 384, 23
+    x = torch.randn(rows, dim, generator=g); br = torch.randn(rows, dim, generator=g).to(TDT[dt])
+    gamma, beta = torch.randn(dim, generator=g), torch.randn(dim, generator=g)
+    rmap = torch.randperm(rows, generator=g)[:n].to(torch.int32)
+    for use_map in (False, True):
+        nr = n if use_map else rows
+        xo = torch.full((rows, dim), 7.0, device=dev)
+        y = torch.empty(nr, dim, dtype=TDT[dt], device=dev); mean = torch.empty(nr, device=dev); rstd = torch.empty(nr, device=dev)
+        check(lib.mae_add_layernorm_fwd(_ptr(dv(x)), _ptr(dv(br)), _ptr(xo), _ptr(dv(rmap)) if use_map else None, _ptr(dv(gamma)),
+                                        _ptr(dv(beta)), 1e-6, nr, dim, dt, _ptr(y), _ptr(mean), _ptr(rstd), stream(dev)))
+        v = x + br.float()
+        sel = rmap.long() if use_map else torch.arange(rows)
+        assert torch.equal(xo.cpu()[sel], v[sel])
+        if use_map:
+            rest = torch.ones(rows, dtype=torch.bool); rest[sel] = False
+            assert bool((xo.cpu()[rest] == 7.0).all())  # rows outside the map are untouched
+        assert rel_err(y.float(), F.layer_norm(v[sel], (dim,), gamma, beta, 1e-6)) < (1e-5 if dt == F32 else 6e-3)
+
+
 # ----------------------------------------------------------------------------------------------- linear
 def _gelu_grad(x):
     return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
