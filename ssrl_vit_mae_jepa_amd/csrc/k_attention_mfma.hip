@@ -74,18 +74,26 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
 }
 
-__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups that share lane&15
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+// reductions across the 4 lane groups that share lane&15 (lanes l, l^16, l^32, l^48), by VALU lane swaps:
+// permlane16_swap(x, x) leaves {own, partner-of-l^16} in the two results for every lane; permlane32_swap likewise for l^32
+__device__ __forceinline__ float group_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 }  // namespace
 
-template <int HD>
+// NCH > 0: the number of 32-token chunks is a compile-time constant, the chunk loops are fully unrolled and the
+// compiler overlaps the MFMA / exp chains of different chunks (a runtime loop serialises them); NCH == 0: any length.
+template <int HD, int NCH>
 __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
                                                             bf16* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,7 +113,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restri
   __syncthreads();
   const int g = lane >> 4, i = lane & 15;
   const float sl2 = scale * kLog2e;
-  const int nq = (T + 15) >> 4, nchunks = Tp >> 5;
+  const int nq = (T + 15) >> 4, nchunks = NCH > 0 ? NCH : (Tp >> 5);
   for (int qt = wave; qt < nq; qt += nwaves) {
     bf16x8 qf[AT<HD>::NKS];
 #pragma unroll
@@ -114,6 +122,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restri
 #pragma unroll
     for (int dt = 0; dt < AT<HD>::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, lsum = 0.f;
+#pragma unroll
     for (int c = 0; c < nchunks; ++c) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -161,7 +170,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restri
   }
 }
 
-template <int HD>
+template <int HD, int NCH>
 __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
                                                             int Tp, int H, float scale, bf16* __restrict__ d_qkv) {
@@ -212,7 +221,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   __syncthreads();
   const int g = lane >> 4, i = lane & 15;
   const float sl2 = scale * kLog2e;
-  const int nt16 = (T + 15) >> 4, nchunks = Tp >> 5;
+  const int nt16 = (T + 15) >> 4, nchunks = NCH > 0 ? NCH : (Tp >> 5);
 
   // ---- phase A: wave owns 16 queries; dQ^T[d][i] = sum_j K^T[d][j] dS^T[j][i]
   for (int qt = wave; qt < nt16; qt += nwaves) {
@@ -226,6 +235,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
     f32x4 dq[AT<HD>::NDT];
 #pragma unroll
     for (int dt = 0; dt < AT<HD>::NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
     for (int c = 0; c < nchunks; ++c) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
 #pragma unroll
@@ -266,6 +276,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
     f32x4 dk[AT<HD>::NDT], dv[AT<HD>::NDT];
 #pragma unroll
     for (int dt = 0; dt < AT<HD>::NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
+#pragma unroll
     for (int c = 0; c < nchunks; ++c) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
 #pragma unroll
@@ -314,22 +325,43 @@ static bool attn_supported(int T, int H, int hd) {
   return (hd == 32 || hd == 64) && T >= 1 && T <= 1024 && ((int64_t)H * hd) % 8 == 0;
 }
 
+template <int HD, int NCH>
+static int launch_attn_fwd(const bf16* qkv, int B, int T, int Tp, int H, size_t lds, float scale, bf16* out, float* lse, hipStream_t s) {
+  auto kern = attn_fwd_mfma_kernel<HD, NCH>;
+  MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T)), lds, s, qkv, T, Tp, H, scale, out, lse);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+template <int HD, int NCH>
+static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int Tp, int H, size_t lds,
+                           float scale, bf16* d_qkv, hipStream_t s) {
+  auto kern = attn_bwd_mfma_kernel<HD, NCH>;
+  MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+#define ATTN_DISPATCH(FN, BIG, ...)                                         \
+  switch (hd * 100 + (Tp >> 5)) {                                           \
+    case 6401: return FN<64, 1>(__VA_ARGS__);                               \
+    case 6402: return FN<64, 2>(__VA_ARGS__);                               \
+    case 6403: return FN<64, 3>(__VA_ARGS__);                               \
+    case 6405: return FN<64, BIG>(__VA_ARGS__);  /* backward: 5 unrolled chunks cost occupancy (217-256 VGPRs): runtime loop */ \
+    case 3201: return FN<32, 1>(__VA_ARGS__);                               \
+    case 3202: return FN<32, 2>(__VA_ARGS__);                               \
+    case 3203: return FN<32, 3>(__VA_ARGS__);                               \
+    case 3205: return FN<32, BIG>(__VA_ARGS__);                             \
+    default: return hd == 64 ? FN<64, 0>(__VA_ARGS__) : FN<32, 0>(__VA_ARGS__); \
+  }
+
 int mfma_attention_fwd(const bf16* qkv, int B, int T, int H, int hd, bf16* out, float* lse, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return MFMA_UNSUPPORTED;
   const int Tp = (int)round_up(T, 32);
   const size_t lds = (size_t)3 * round_up((int64_t)Tp * (hd * 2 + 32), 1024);
   if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
   const float scale = 1.0f / sqrtf((float)hd);
-  const dim3 grid((unsigned)B * H), block(64 * attn_waves(T));
-  if (hd == 64) {
-    MAE_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((attn_fwd_mfma_kernel<64>), grid, block, lds, s, qkv, T, Tp, H, scale, out, lse);
-  } else {
-    MAE_HIP(hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((attn_fwd_mfma_kernel<32>), grid, block, lds, s, qkv, T, Tp, H, scale, out, lse);
-  }
-  MAE_LAUNCH_CHECK();
-  return 0;
+  ATTN_DISPATCH(launch_attn_fwd, 5, qkv, B, T, Tp, H, lds, scale, out, lse, s)
 }
 
 int mfma_attention_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int H, int hd,
@@ -339,16 +371,7 @@ int mfma_attention_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, cons
   const size_t lds = (size_t)4 * round_up((int64_t)Tp * (hd * 2 + 32), 1024) + (size_t)2 * Tp * 4;
   if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
   const float scale = 1.0f / sqrtf((float)hd);
-  const dim3 grid((unsigned)B * H), block(64 * attn_waves(T));
-  if (hd == 64) {
-    MAE_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((attn_bwd_mfma_kernel<64>), grid, block, lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv);
-  } else {
-    MAE_HIP(hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((attn_bwd_mfma_kernel<32>), grid, block, lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv);
-  }
-  MAE_LAUNCH_CHECK();
-  return 0;
+  ATTN_DISPATCH(launch_attn_bwd, 0, qkv, out, d_out, lse, B, T, Tp, H, lds, scale, d_qkv, s)
 }
 
 }  // namespace mae
