@@ -6,6 +6,7 @@
 #include <vector>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace mae {
@@ -66,6 +67,13 @@ struct mae_engine {
   std::vector<BlockRefs> enc, dec;
   bool timers_on = false;
   TimerSlot timers[TK_COUNT];
+  // weight-gradient GEMMs are off the backward critical path (their results are only read by the optimizer): they
+  // are enqueued on a side stream so they overlap the HBM-bound LayerNorm / attention backward kernels of the main chain
+  int side_mode = -1;  // -1 = undecided, 0 = off, 1 = on
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  hipEvent_t pending[4] = {nullptr, nullptr, nullptr, nullptr};  // last side-stream reader of dres_c / d_hidden / d_qkv / one-off buffers
 };
 
 namespace mae {
@@ -215,6 +223,36 @@ struct TimerScope {
   } while (0)
 
 // ---------------------------------------------------------------------------------------------------
+// side stream for the weight-gradient GEMMs
+// ---------------------------------------------------------------------------------------------------
+enum DepTag { DEP_DRESC = 0, DEP_HIDDEN = 1, DEP_QKV = 2, DEP_MISC = 3 };
+
+static bool side_enabled(mae_engine* e) {
+  if (e->side_mode < 0) {
+    const char* v = getenv("MAE_WGRAD_STREAM");  // opt-in: measured neutral on MI355X (the GEMMs already fill every CU)
+    e->side_mode = (v && v[0] == '1') ? 1 : 0;
+    if (e->side_mode == 1 && hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side_mode = 0;
+  }
+  return e->side_mode == 1;
+}
+static hipEvent_t next_event(mae_engine* e) {
+  if (e->ev_used == e->ev_pool.size()) {
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    e->ev_pool.push_back(ev);
+  }
+  return e->ev_pool[e->ev_used++];
+}
+// the main stream must not overwrite a buffer the side stream may still be reading
+static int await_side(mae_engine* e, int tag, hipStream_t s) {
+  if (e->pending[tag]) {
+    MAE_HIP(hipStreamWaitEvent(s, e->pending[tag], 0));
+    e->pending[tag] = nullptr;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // helpers bound to one call
 // ---------------------------------------------------------------------------------------------------
 struct Ctx {
@@ -259,10 +297,38 @@ static int dgrad(const Ctx& c, const void* dY, int wi, int64_t M, int N, int K, 
   return 0;
 }
 
-static int wgrad(const Ctx& c, const Plan& pl, const void* dY, const void* A, int64_t M, int N, int K, int wi, int bi) {
-  mae_engine* e = c.e; hipStream_t s = c.s;
+static int wgrad(const Ctx& c, const Plan& pl, const void* dY, const void* A, int64_t M, int N, int K, int wi, int bi, int tag) {
+  mae_engine* e = c.e;
+  hipStream_t s = c.s;
+  const bool side = side_enabled(e);
+  if (side) {  // fork: the side stream waits for everything enqueued so far (the producer of dY)
+    hipEvent_t ready = next_event(e);
+    MAE_REQUIRE(ready, "wgrad: cannot create an event");
+    MAE_HIP(hipEventRecord(ready, c.s));
+    MAE_HIP(hipStreamWaitEvent(e->side, ready, 0));
+    s = e->side;
+  }
   RUN(TK_WGRAD, 2.0 * M * N * K, (double)(M * (N + K) * c.as + (int64_t)N * K * 4),
       launch_linear_wgrad(dY, A, M, N, K, c.act, c.Gp(wi), bi >= 0 ? c.Gp(bi) : nullptr, c.buf<>(pl.wgrad_scratch), s));
+  if (side) {
+    hipEvent_t done = next_event(e);
+    MAE_REQUIRE(done, "wgrad: cannot create an event");
+    MAE_HIP(hipEventRecord(done, e->side));
+    e->pending[tag] = done;
+  }
+  return 0;
+}
+
+// join: everything on the side stream is finished before the main stream continues
+static int join_side(const Ctx& c) {
+  mae_engine* e = c.e;
+  if (e->side_mode == 1) {
+    hipEvent_t done = next_event(e);
+    MAE_REQUIRE(done, "cannot create an event");
+    MAE_HIP(hipEventRecord(done, e->side));
+    MAE_HIP(hipStreamWaitEvent(c.s, done, 0));
+    for (auto& p : e->pending) p = nullptr;
+  }
   return 0;
 }
 
@@ -297,17 +363,21 @@ static int block_backward(const Ctx& c, const Plan& pl, const BlockRefs& r, cons
   void* dres_c = c.buf<>(pl.dres_c);
   float* lnp = c.buf<float>(pl.ln_partial);
   // MLP branch
-  MAE_TRY(wgrad(c, pl, dres_c, c.buf<>(b.fc1_act), M, d, hid, r.fc2_w, r.fc2_b));
+  MAE_TRY(wgrad(c, pl, dres_c, c.buf<>(b.fc1_act), M, d, hid, r.fc2_w, r.fc2_b, DEP_DRESC));
+  MAE_TRY(await_side(e, DEP_HIDDEN, s));  // the previous block's fc1 wgrad reads d_hidden
   MAE_TRY(dgrad(c, dres_c, r.fc2_w, M, d, hid, MAE_EPI_MUL, c.buf<>(pl.d_hidden), c.buf<>(b.fc1_pre)));
-  MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_hidden), c.buf<>(b.ln2), M, hid, d, r.fc1_w, r.fc1_b));
+  MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_hidden), c.buf<>(b.ln2), M, hid, d, r.fc1_w, r.fc1_b, DEP_HIDDEN));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_hidden), r.fc1_w, M, hid, d, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
+  MAE_TRY(await_side(e, DEP_DRESC, s));  // fc2 wgrad reads dres_c, which this kernel rewrites
   RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), M, d, 1, dres, dres_c, c.Gp(r.ln2_w), c.Gp(r.ln2_b), lnp, s));
   // attention branch
-  MAE_TRY(wgrad(c, pl, dres_c, c.buf<>(b.att), M, d, d, r.proj_w, r.proj_b));
+  MAE_TRY(wgrad(c, pl, dres_c, c.buf<>(b.att), M, d, d, r.proj_w, r.proj_b, DEP_DRESC));
   MAE_TRY(dgrad(c, dres_c, r.proj_w, M, d, d, MAE_EPI_NONE, c.buf<>(pl.d_att), nullptr));
+  MAE_TRY(await_side(e, DEP_QKV, s));  // the previous block's qkv wgrad reads d_qkv
   RUN(TK_ATTN_BWD, 10.0 * Bn * heads * (double)T * T * hd, M * 9 * d * c.as, launch_attention_bwd(c.buf<>(b.qkv), c.buf<>(b.att), c.buf<>(pl.d_att), c.buf<float>(b.lse), Bn, T, heads, hd, c.act, c.buf<>(pl.d_qkv), s));
-  MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_qkv), c.buf<>(b.ln1), M, 3 * d, d, r.qkv_w, r.qkv_b));
+  MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_qkv), c.buf<>(b.ln1), M, 3 * d, d, r.qkv_w, r.qkv_b, DEP_QKV));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_qkv), r.qkv_w, M, 3 * d, d, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
+  MAE_TRY(await_side(e, DEP_DRESC, s));  // proj wgrad reads dres_c
   RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(x_in), nullptr, c.P(r.ln1_w), c.buf<float>(b.mean1), c.buf<float>(b.rstd1), M, d, 1, dres, dres_c, c.Gp(r.ln1_w), c.Gp(r.ln1_b), lnp, s));
   return 0;
 }
@@ -360,13 +430,16 @@ static int forward_decoder_impl(const Ctx& c, const Plan& pl, float* x_pred_out)
 // dpred (act dtype) must already sit in the workspace
 static int backward_impl(const Ctx& c, const Plan& pl) {
   mae_engine* e = c.e; hipStream_t s = c.s;
+  e->ev_used = 0;
+  for (auto& p : e->pending) p = nullptr;
   float* dres = c.buf<float>(pl.dres);
   void* dres_c = c.buf<>(pl.dres_c);
   float* lnp = c.buf<float>(pl.ln_partial);
   // prediction head
-  MAE_TRY(wgrad(c, pl, c.buf<>(pl.dpred), c.buf<>(pl.dec_norm), pl.Mp, e->P, e->Dd, e->i_pred_w, e->i_pred_b));
+  MAE_TRY(wgrad(c, pl, c.buf<>(pl.dpred), c.buf<>(pl.dec_norm), pl.Mp, e->P, e->Dd, e->i_pred_w, e->i_pred_b, DEP_MISC));
   MAE_TRY(dgrad(c, c.buf<>(pl.dpred), e->i_pred_w, pl.Mp, e->P, e->Dd, MAE_EPI_NONE, c.buf<>(pl.d_decn), nullptr));
   // decoder_norm over the masked rows only: every other row of the residual gradient is zero
+  MAE_TRY(await_side(e, DEP_DRESC, s));
   MAE_HIP(hipMemsetAsync(dres, 0, (size_t)pl.Md * e->Dd * 4, s));
   MAE_HIP(hipMemsetAsync(dres_c, 0, (size_t)pl.Md * e->Dd * c.as, s));
   RUN(TK_LN_BWD, 0, pl.Mp * e->Dd * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_decn), c.act, c.buf<float>(pl.dec_x[e->dd]), c.buf<int32_t>(pl.pred_rows), c.P(e->i_dn_w), c.buf<float>(pl.dec_mean), c.buf<float>(pl.dec_rstd), pl.Mp, e->Dd, 0, dres, dres_c, c.Gp(e->i_dn_w), c.Gp(e->i_dn_b), lnp, s));
@@ -374,16 +447,17 @@ static int backward_impl(const Ctx& c, const Plan& pl) {
     MAE_TRY(block_backward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.B, e->L, pl.dec_x[i]));
   RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_decoder_assemble_bwd(dres, c.buf<int32_t>(pl.inv), c.buf<int32_t>(pl.keep32), pl.B, pl.k, e->L, e->Dd, c.act, c.buf<>(pl.d_xdec), c.Gp(e->i_dec_mask), c.buf<float>(pl.split_partial), s));
   // decoder_embed
-  MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_xdec), c.buf<>(pl.enc_norm), pl.Me, e->Dd, e->D, e->i_de_w, e->i_de_b));
+  MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_xdec), c.buf<>(pl.enc_norm), pl.Me, e->Dd, e->D, e->i_de_w, e->i_de_b, DEP_MISC));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_xdec), e->i_de_w, pl.Me, e->Dd, e->D, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
   // encoder final norm
+  MAE_TRY(await_side(e, DEP_DRESC, s));
   RUN(TK_LN_BWD, 0, pl.Me * e->D * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(pl.enc_x[e->depth]), nullptr, c.P(e->i_norm_w), c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), pl.Me, e->D, 0, dres, dres_c, c.Gp(e->i_norm_w), c.Gp(e->i_norm_b), lnp, s));
   for (int i = e->depth - 1; i >= 0; --i)
     MAE_TRY(block_backward(c, pl, e->enc[i], pl.enc[i], pl.Me, e->D, e->H, pl.B, pl.k, pl.enc_x[i]));
   // token assembly and patch projection
   RUN(TK_DATA, 0, pl.Me * e->D * (4 + c.as), launch_visible_grad_split(dres, c.buf<int32_t>(pl.keep32), pl.Me, e->D, c.act, c.buf<>(pl.dtok), c.Gp(e->i_cls), c.buf<float>(pl.split_partial), s));
-  MAE_TRY(wgrad(c, pl, c.buf<>(pl.dtok), c.buf<>(pl.patchA), pl.Me, e->D, e->P, e->i_patch_w, e->i_patch_b));
-  return 0;
+  MAE_TRY(wgrad(c, pl, c.buf<>(pl.dtok), c.buf<>(pl.patchA), pl.Me, e->D, e->P, e->i_patch_w, e->i_patch_b, DEP_MISC));
+  return join_side(c);
 }
 
 }  // namespace mae
@@ -455,6 +529,8 @@ extern "C" void mae_engine_destroy(mae_engine_t* e) {
   if (!e) return;
   for (auto& t : e->timers)
     for (auto& pr : t.ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (auto ev : e->ev_pool) (void)hipEventDestroy(ev);
+  if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
 }
 

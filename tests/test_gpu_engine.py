@@ -250,3 +250,23 @@ def test_pretrain_cli_synthetic_run_and_resume(dev, tmp_path, monkeypatch):
               "--resume_from", str(out / "checkpoints" / "last.ckpt")])
     ck2 = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
     assert ck2["epoch"] == 2 and ck2["global_step"] > ck["global_step"]
+
+
+def test_side_stream_wgrad_is_bitwise_identical(dev, monkeypatch):
+    """Weight-gradient GEMMs run on a side stream (overlapping the LayerNorm / attention backward of the main chain);
+    the event dependencies must make that invisible: same bits as the single-stream order."""
+    cfg, B = O.VIT_S8_YAMLDEC, 64
+    g = torch.Generator(device=dev).manual_seed(3)
+    images = torch.rand(B, 3, 96, 96, device=dev, generator=g) * 2 - 1
+    noise = torch.rand(B, cfg.sequence_length, device=dev, generator=g)
+    results = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MAE_WGRAD_STREAM", mode)
+        torch.manual_seed(5)
+        model = MaskedAutoencoder(*cfg_dicts(cfg, "bf16")).to(dev)
+        losses = []
+        for _ in range(3):
+            losses.append(model.loss_and_grads(images, noise).clone())
+        torch.cuda.synchronize()
+        results.append((torch.cat(losses).cpu(), model.flat_grads.clone().cpu()))
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
