@@ -22,18 +22,23 @@ namespace mae {
 
 namespace {
 
-constexpr int BM2 = 256, BK2 = 64;
+constexpr int BK2 = 64;
 
-template <int NI>
-struct Geo {  // NI = 16-column MFMA tiles per wave along N (2 waves along N): BN = 32 NI = 128 or 192
-  static constexpr int BN = 32 * NI;
-  static constexpr int STAGE = (BM2 + BN) * BK2 * 2;              // A rows first, then W rows, 128 B per row
-  static constexpr int NSTAGE = NI == 4 ? 3 : 2;                   // 3 x 48 KiB or 2 x 56 KiB
+// NI = 16-column MFMA tiles per wave along N (2 waves along N): BN = 32 NI = 128 or 192
+// MI = 16-row MFMA tiles per wave along M (4 waves along M):    BM = 64 MI = 256 or 192.  The 192-row tile exists for
+//      load balance: with N = 384 a 72 000-row GEMM has 564 tiles of 256x192 (2.2 per CU -> 3 rounds, 73 % busy) but
+//      750 tiles of 192x192 (2.93 per CU -> 3 shorter rounds, 98 % busy).
+template <int NI, int MI>
+struct Geo {
+  static constexpr int BN = 32 * NI, BM = 64 * MI;
+  static constexpr int STAGE = (BM + BN) * BK2 * 2;               // A rows first, then W rows, 128 B per row
+  static constexpr int NSTAGE = (3 * STAGE + 2 * BN * 4 <= 160 * 1024) ? 3 : 2;
   static constexpr int AHEAD = NSTAGE - 1;                         // K-steps of DMA in flight during a compute phase
   static constexpr int BIAS_OFF = NSTAGE * STAGE;                  // [2 tiles][BN] floats
   static constexpr int LDS = BIAS_OFF + 2 * BN * 4;
-  static constexpr int GPW = (BM2 + BN) / 8 / 8;                   // 1 KiB DMA groups (8 rows) per wave and stage: 6 or 7
+  static constexpr int GPW = (BM + BN) / 8 / 8;                    // 1 KiB DMA groups (8 rows) per wave and stage: 5..7
   static constexpr int NBIAS = BN / 64;                            // 256-byte bias DMAs per wave at the first K-step of a tile
+  static_assert((BM + BN) % 64 == 0, "DMA groups must divide evenly over the 8 waves");
 };
 
 __device__ __forceinline__ void ld8(const float* p, f32x4& a, f32x4& b) { a = load4(p); b = load4(p + 4); }
@@ -67,19 +72,21 @@ __device__ __forceinline__ void wait_vm() {
 }  // namespace
 
 // MODE: any MAE_EPI_*.  RESID / DGELU read their (M,N) side input with ordinary loads in the epilogue.
-template <int MODE, class TO, bool HAS_BIAS, int NI>
+template <int MODE, class TO, bool HAS_BIAS, int NI, int MI>
 __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M, int N,
                                                           int K, const float* __restrict__ bias, const void* __restrict__ aux,
                                                           TO* __restrict__ out, TO* __restrict__ out2, int tiles_m, int tiles_n) {
-  using G_ = Geo<NI>;
+  using G_ = Geo<NI, MI>;
+  constexpr int BM2 = G_::BM;
   constexpr int BN = G_::BN, STAGE = G_::STAGE, NSTAGE = G_::NSTAGE, AHEAD = G_::AHEAD, GPW = G_::GPW;
   constexpr int NB = HAS_BIAS ? G_::NBIAS : 0;
   constexpr int STORE8 = sizeof(TO) == 2 ? 1 : 2;                                // store instructions per 8 outputs
-  constexpr int E = 4 * (NI / 2) * STORE8 * ((MODE == MAE_EPI_GELU || MODE == MAE_EPI_GELU_GRAD) ? 2 : 1);      // epilogue stores per wave (full tile)
+  constexpr int E = MI * (NI / 2) * STORE8 * ((MODE == MAE_EPI_GELU || MODE == MAE_EPI_GELU_GRAD) ? 2 : 1);      // epilogue stores per wave (full tile)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  constexpr int WROWS = 16 * MI;  // rows of the tile owned by one wave
   const int fr = lane & 15, fq = lane >> 4;
   const int G = gridDim.x, T = tiles_m * tiles_n;
   const int vb = (int)xcd_remap2(blockIdx.x, G);
@@ -90,7 +97,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
   // ---- producer side: this wave's DMA groups of a stage (group g < 32: A rows 8g.., else W rows 8(g-32)..)
   const int r8 = lane >> 3;
   const int src_chunk = ((lane & 7) ^ r8) * 8;  // swizzled source chunk (elements) for LDS slot lane&7 of row r8
-  const bf16 *p0, *p1, *p2, *p3, *p4, *p5, *p6 = nullptr;
+  const bf16 *p0, *p1, *p2, *p3, *p4, *p5 = nullptr, *p6 = nullptr;
   const float* pbias = bias;
   int is_tile = 0, is_k = 0, is_stage = 0;
   auto src_ptr = [&](int q, int64_t m0, int n0) -> const bf16* {
@@ -107,7 +114,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
     const int64_t m0 = (int64_t)(t / tiles_n) * BM2;
     const int n0 = (t % tiles_n) * BN;
     p0 = src_ptr(0, m0, n0); p1 = src_ptr(1, m0, n0); p2 = src_ptr(2, m0, n0);
-    p3 = src_ptr(3, m0, n0); p4 = src_ptr(4, m0, n0); p5 = src_ptr(5, m0, n0);
+    p3 = src_ptr(3, m0, n0); p4 = src_ptr(4, m0, n0);
+    if (GPW > 5) p5 = src_ptr(5, m0, n0);
     if (GPW > 6) p6 = src_ptr(6, m0, n0);
     if (HAS_BIAS) pbias = bias + n0 + lane;
   };
@@ -119,7 +127,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
     glds16(p2 + ko, dst + 2048);
     glds16(p3 + ko, dst + 3072);
     glds16(p4 + ko, dst + 4096);
-    glds16(p5 + ko, dst + 5120);
+    if (GPW > 5) glds16(p5 + ko, dst + 5120);
     if (GPW > 6) glds16(p6 + ko, dst + 6144);
     if (HAS_BIAS && is_k == 0) {  // the tile's bias strip rides with its first K-step (every wave writes the same bytes)
       char* bdst = smem + G_::BIAS_OFF + (is_tile & 1) * (BN * 4);
@@ -133,9 +141,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
     }
   };
 
-  f32x4 acc[4][NI];
+  f32x4 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -162,24 +170,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const char* a_base = smem + cs * STAGE + (wm * 64 + fr) * 128;
+    const char* a_base = smem + cs * STAGE + (wm * WROWS + fr) * 128;
     const char* b_base = smem + cs * STAGE + BM2 * 128 + (wn * (NI * 16) + fr) * 128;
     // fragments of both 32-deep halves are read up front, the DMA refill is issued between the two read bursts
-    bf16x8 af[2][4], bfr[2][NI];
+    bf16x8 af[2][MI], bfr[2][NI];
     const int sw0 = ((0 + fq) ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) af[0][mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw0);
+    for (int mi = 0; mi < MI; ++mi) af[0][mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw0);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) bfr[0][ni] = *reinterpret_cast<const bf16x8*>(b_base + ni * 16 * 128 + sw0);
     if (step + AHEAD < nsteps) issue();  // refills the stage every wave finished reading in the previous iteration
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) af[1][mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw1);
+    for (int mi = 0; mi < MI; ++mi) af[1][mi] = *reinterpret_cast<const bf16x8*>(a_base + mi * 16 * 128 + sw1);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) bfr[1][ni] = *reinterpret_cast<const bf16x8*>(b_base + ni * 16 * 128 + sw1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
       const int64_t m0 = (int64_t)(t / tiles_n) * BM2;
       const int n0 = (t % tiles_n) * BN;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int j = 0; j < NI / 2; ++j)
 #pragma unroll
@@ -207,8 +215,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
         if (HAS_BIAS) { b0 = load4(sbias + nl); b1 = load4(sbias + nl + 4); }
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-          const int64_t m = m0 + wm * 64 + mi * 16 + fr;
+        for (int mi = 0; mi < MI; ++mi) {
+          const int64_t m = m0 + wm * WROWS + mi * 16 + fr;
           if (m < M) {
             const int64_t o = m * N + n0 + wn * (NI * 16) + nl;
             f32x4 v0 = acc[mi][2 * j] + b0, v1 = acc[mi][2 * j + 1] + b1;
@@ -264,19 +272,19 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
   }
 }
 
-template <int MODE, class TO, int NI>
+template <int MODE, class TO, int NI, int MI>
 static int launch_nt2(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
-  using G_ = Geo<NI>;
-  const int64_t T = cdiv(M, BM2) * (N / G_::BN);
+  using G_ = Geo<NI, MI>;
+  const int64_t T = cdiv(M, G_::BM) * (N / G_::BN);
   MAE_REQUIRE(T < (1ll << 30), "gemm: too many tiles");
-  const int tiles_m = (int)cdiv(M, BM2), tiles_n = N / G_::BN;
+  const int tiles_m = (int)cdiv(M, G_::BM), tiles_n = N / G_::BN;
   const int grid = (int)std::min<int64_t>(T, 256);
   if (e.bias) {
-    auto kern = gemm_nt2_kernel<MODE, TO, true, NI>;
+    auto kern = gemm_nt2_kernel<MODE, TO, true, NI, MI>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
   } else {
-    auto kern = gemm_nt2_kernel<MODE, TO, false, NI>;
+    auto kern = gemm_nt2_kernel<MODE, TO, false, NI, MI>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
   }
@@ -284,10 +292,21 @@ static int launch_nt2(const bf16* A, const bf16* W, int64_t M, int N, int K, con
   return 0;
 }
 
+// rounds of tiles on the 256 CUs x rows per tile = time proxy; the 192-row tile must win by a margin because it stages
+// 15 % more operand bytes per flop
+static bool prefer_bm192(int64_t M, int N) {
+  const int64_t t256 = cdiv(M, 256) * (N / 192), t192 = cdiv(M, 192) * (N / 192);
+  const int64_t c256 = cdiv(t256, 256) * 256, c192 = cdiv(t192, 256) * 192;
+  return c192 * 100 < c256 * 88;
+}
+
 template <int MODE, class TO>
 static int launch_nt2_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
-  if (N % 192 == 0) return launch_nt2<MODE, TO, 6>(A, W, M, N, K, e, s);
-  return launch_nt2<MODE, TO, 4>(A, W, M, N, K, e, s);
+  if (N % 192 == 0) {
+    if (prefer_bm192(M, N)) return launch_nt2<MODE, TO, 6, 3>(A, W, M, N, K, e, s);
+    return launch_nt2<MODE, TO, 6, 4>(A, W, M, N, K, e, s);
+  }
+  return launch_nt2<MODE, TO, 4, 4>(A, W, M, N, K, e, s);
 }
 
 int mfma_linear_fwd_v2(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
