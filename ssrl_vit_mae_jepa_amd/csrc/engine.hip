@@ -563,12 +563,24 @@ extern "C" int64_t mae_engine_wcache_bytes(const mae_engine_t* e) {
 
 static int refresh_transposed(mae_engine* e, const float* params, void* wcache, hipStream_t s) {
   bf16* tbase = reinterpret_cast<bf16*>(wcache) + e->trainable_elems;
+  TransposeTable tab;
+  auto flush = [&]() -> int {
+    if (tab.n == 0) return 0;
+    tab.total_tiles = tab.tile_begin[tab.n];
+    const int r = launch_transpose_many(params, tbase, tab, s);
+    tab.n = 0;
+    return r;
+  };
+  tab.tile_begin[0] = 0;
   for (const auto& pi : e->params) {
     if (!(pi.flags & MAE_PARAM_MATRIX) || pi.t_off < 0) continue;
     const int rows = (int)pi.shape[0], cols = (int)(pi.numel / pi.shape[0]);
-    MAE_TRY(launch_transpose_to_bf16(params + pi.offset, tbase + pi.t_off, rows, cols, s));
+    const int i = tab.n++;
+    tab.src_off[i] = pi.offset; tab.dst_off[i] = pi.t_off; tab.rows[i] = rows; tab.cols[i] = cols;
+    tab.tile_begin[i + 1] = tab.tile_begin[i] + (int)(cdiv(rows, 32) * cdiv(cols, 32));
+    if (tab.n == TransposeTable::MAX) { MAE_TRY(flush()); tab.tile_begin[0] = 0; }
   }
-  return 0;
+  return flush();
 }
 
 extern "C" int mae_engine_refresh_weights(mae_engine_t* e, const float* params, void* wcache, void* stream) {

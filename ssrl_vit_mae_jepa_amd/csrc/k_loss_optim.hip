@@ -218,6 +218,37 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const float* __rest
   }
 }
 
+// every GEMM weight in ONE launch: the matrix table travels as a kernel argument (<= 64 entries); block b finds its matrix
+// by a scan over the cumulative 32x32-tile counts
+__global__ void __launch_bounds__(256) transpose_many_kernel(const float* __restrict__ params, bf16* __restrict__ tbase, TransposeTable tab) {
+  __shared__ float tile[32][33];
+  int i = 0;
+  while (i + 1 < tab.n && (int)blockIdx.x >= tab.tile_begin[i + 1]) ++i;
+  const int rows = tab.rows[i], cols = tab.cols[i];
+  const int local = blockIdx.x - tab.tile_begin[i];
+  const int tiles_c = (cols + 31) >> 5;
+  const int r0 = (local / tiles_c) * 32, c0 = (local % tiles_c) * 32;
+  const float* src = params + tab.src_off[i];
+  bf16* dst = tbase + tab.dst_off[i];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < cols && r < rows) dst[(int64_t)c * rows + r] = (bf16)tile[tx][k];
+  }
+}
+
+int launch_transpose_many(const float* params, bf16* tbase, const TransposeTable& tab, hipStream_t s) {
+  MAE_REQUIRE(params && tbase && tab.n > 0 && tab.n <= TransposeTable::MAX, "transpose_many: bad table");
+  hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)tab.total_tiles), dim3(256), 0, s, params, tbase, tab);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_transpose_to_bf16(const float* src, bf16* dst, int rows, int cols, hipStream_t s) {
   MAE_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose_to_bf16: bad arguments");
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((int)cdiv(cols, 32), (int)cdiv(rows, 32)), dim3(256), 0, s, src, dst, rows, cols);

@@ -55,6 +55,14 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
 int launch_f32_to_bf16(const float* src, bf16* dst, int64_t n, hipStream_t s);
 // dst[c][r] = (bf16) src[r][c]
 int launch_transpose_to_bf16(const float* src, bf16* dst, int rows, int cols, hipStream_t s);
+// the same for a whole list of matrices living in one arena (one launch); passed by value as a kernel argument
+struct TransposeTable {
+  static constexpr int MAX = 64;
+  int n = 0, total_tiles = 0;
+  int64_t src_off[MAX], dst_off[MAX];
+  int rows[MAX], cols[MAX], tile_begin[MAX + 1];
+};
+int launch_transpose_many(const float* params, bf16* tbase, const TransposeTable& tab, hipStream_t s);
 
 // ---- k_layernorm.hip --------------------------------------------------------------------------------
 // y = LN(x [+ branch]); with a branch (dtype y_dt) the sum is also written to x_out (fp32): the fused residual add
