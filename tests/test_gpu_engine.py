@@ -270,3 +270,63 @@ def test_side_stream_wgrad_is_bitwise_identical(dev, monkeypatch):
         torch.cuda.synchronize()
         results.append((torch.cat(losses).cpu(), model.flat_grads.clone().cpu()))
     assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ViT-S/8 geometry (the MFMA kernels' shapes) at other mask ratios: k = 72 / 36 / 21 visible tokens
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("r,B", [(0.5, 6), (0.75, 7), (0.86, 9)])
+def test_vits8_bf16_matches_emulating_oracle_at_other_mask_ratios(dev, r, B):
+    cfg = O.VIT_S8_YAMLDEC
+    model, params = build(cfg, "bf16", dev, r)
+    images = O.synthetic_images(B, cfg)
+    noise = O.make_noise(B, cfg.sequence_length, torch.Generator().manual_seed(5))
+    loss_emu, grads_emu, aux = O.loss_and_grads(params, cfg, images, noise, r, bf16=True)
+    loss, keep, mask = model.loss_and_grads(images.to(dev), noise.to(dev), return_indices=True)
+    assert keep.shape[1] == cfg.num_keep(r) and torch.equal(keep.cpu(), aux["idx_keep"]) and torch.equal(mask.cpu(), aux["idx_mask"])
+    assert abs(loss.item() - loss_emu.item()) <= 5e-3 * abs(loss_emu.item())
+    g = model.named_flat_views(model.flat_grads)
+    num = sum(float((g[n].double().cpu() - gr.double()).pow(2).sum()) for n, gr in grads_emu.items())
+    den = sum(float(gr.double().pow(2).sum()) for gr in grads_emu.values())
+    assert (num / den) ** 0.5 < 5e-2
+
+
+def test_vits8_fp32_matches_oracle(dev):
+    cfg, B, r = O.VIT_S8_YAMLDEC, 3, 0.75
+    model, params = build(cfg, "fp32", dev, r)
+    images = O.synthetic_images(B, cfg)
+    noise = O.make_noise(B, cfg.sequence_length, torch.Generator().manual_seed(5))
+    loss_ref, grads_ref, aux = O.loss_and_grads(params, cfg, images, noise, r)
+    loss = model.loss_and_grads(images.to(dev), noise.to(dev))
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    g = model.named_flat_views(model.flat_grads)
+    num = sum(float((g[n].double().cpu() - gr.double()).pow(2).sum()) for n, gr in grads_ref.items())
+    den = sum(float(gr.double().pow(2).sum()) for gr in grads_ref.values())
+    assert (num / den) ** 0.5 < 2e-4
+
+
+def test_step_is_hip_graph_capturable(dev):
+    """The engine only enqueues on the caller's stream (no allocation, no sync): after one eager call (lazy attribute
+    setup) a whole step can be captured into a graph and replayed with the same bits."""
+    cfg, B = MICRO, 4
+    g, e, d = cfg_dicts(cfg, "bf16")
+    tcfg = dict(mask_ratio_start=0.75, mask_ratio_end=0.75, mask_ramp_epochs=5, total_epochs=800, warmup_epochs=20,
+                batch_size=2000, base_learning_rate=1.5e-4, weight_decay=0.05)
+    torch.manual_seed(0)
+    module = MAEPretrainModule(dict(general=g, encoder=e, decoder=d), tcfg).to(dev)
+    images = O.synthetic_images(B, cfg).to(dev)
+    noise = O.make_noise(B, cfg.sequence_length, torch.Generator().manual_seed(1)).to(dev)
+    model = module.model
+    eager = model.loss_and_grads(images, noise).clone()   # warm-up: workspace, weight cache, function attributes
+    grads_eager = model.flat_grads.clone()
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        model.loss_and_grads(images, noise)  # once more on the capture stream before capturing
+        with torch.cuda.graph(graph, stream=stream):
+            loss_static = model.loss_and_grads(images, noise)
+    model.flat_grads.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_static, eager) and torch.equal(model.flat_grads, grads_eager)
