@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Throughput of the fused pretrain step for an arbitrary configs/*.yaml model (GPU box).
+    python tools/bench_config.py --config configs/mae.yaml --batch 2000 --steps 10"""
+import argparse, sys, time
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch, yaml  # noqa: E402
+from ssrl_vit_mae_jepa_amd import MAEPretrainModule  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="configs/mae.yaml")
+ap.add_argument("--batch", type=int, default=2000)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--precision", default="bf16")
+a = ap.parse_args()
+cfg = yaml.safe_load(open(a.config))
+m = cfg["model"]
+m = dict(m, general=dict(m["general"], engine_precision=a.precision))
+dev = torch.device("cuda:0")
+module = MAEPretrainModule(m, dict(cfg["pretrain"], batch_size=a.batch)).to(dev)
+module.on_train_epoch_start()
+L = module.model.sequence_length
+g = torch.Generator(device=dev).manual_seed(73)
+img = m["general"]["image_size"]
+images = torch.rand(a.batch, m["general"].get("in_chans", 3), img, img, device=dev, generator=g) * 2 - 1
+noises = [torch.rand(a.batch, L, device=dev, generator=g) for _ in range(a.steps + 3)]
+for i in range(3):
+    module.fused_training_step(images, noises[i])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(a.steps):
+    loss = module.fused_training_step(images, noises[3 + i])
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.steps
+print(f"{a.config} {a.precision} batch {a.batch}: {1e3 * dt:.2f} ms/step, {a.batch / dt:,.0f} images/s, loss {loss.item():.4f}")
