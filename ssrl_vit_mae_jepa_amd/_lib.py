@@ -11,7 +11,7 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libmae_hip.so"
+LIB_PATH = Path(os.environ.get("MAE_HIP_LIB") or _HERE / "lib" / "libmae_hip.so")  # MAE_HIP_LIB: an alternate build of the same library (kernel experiments)
 
 MAE_F32, MAE_BF16 = 0, 1
 PARAM_TRAINABLE, PARAM_FROZEN, PARAM_UNUSED, PARAM_MATRIX = 1, 2, 4, 8

@@ -300,12 +300,22 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
   const int lane_off = (4 * g + q) * TN_RS + p * 8;
 
   const int64_t nsteps = (mend - mbeg + BR - 1) / BR;
+#ifndef MAE_DBG_TN_NO_LOAD
   TN_G_LOAD(mbeg)
+#else
+  for (int i = 0; i < YC; ++i) ry[i] = uint4{0, 0, 0, 0};
+  for (int i = 0; i < XC; ++i) rx[i] = uint4{0, 0, 0, 0};
+#endif
   for (int64_t st = 0; st < nsteps; ++st) {
     const int buf = (int)(st & 1);
     TN_S_STORE(buf)
     __syncthreads();
+#ifndef MAE_DBG_TN_NO_LOAD
     if (st + 1 < nsteps) TN_G_LOAD(mbeg + (st + 1) * BR)
+#endif
+#ifdef MAE_DBG_TN_NO_MFMA
+    continue;
+#endif
     const char* yb = sY + buf * Y_BYTES + lane_off + (wn * NI * 16) * 2;
     const char* xb = sX + buf * X_BYTES + lane_off + (wk * KI * 16) * 2;
 #pragma unroll

@@ -42,16 +42,23 @@ struct Geo {
 };
 
 __device__ __forceinline__ void ld8(const float* p, f32x4& a, f32x4& b) { a = load4(p); b = load4(p + 4); }
-__device__ __forceinline__ void ld8(const bf16* p, f32x4& a, f32x4& b) {
-  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+__device__ __forceinline__ void unpack8(const bf16x8& v, f32x4& a, f32x4& b) {
   a = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   b = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
 }
-__device__ __forceinline__ void st8(float* p, const f32x4& a, const f32x4& b) { store4(p, a); store4(p + 4, b); }
-__device__ __forceinline__ void st8(bf16* p, const f32x4& a, const f32x4& b) {
-  *reinterpret_cast<bf16x8*>(p) = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+__device__ __forceinline__ void ld8(const bf16* p, f32x4& a, f32x4& b) { unpack8(*reinterpret_cast<const bf16x8*>(p), a, b); }
+// Outputs are written once and read by a LATER kernel: non-temporal stores stream them to HBM instead of parking the
+// lines in L2 until eviction, which both frees L2 for the A / W re-reads and spreads the write traffic over the tile loop
+// (measured: fc1 + GELU forward 220 -> 170 us, decoder fc1 332 -> 242 us).
+// (a per-launch runtime choice between the two store forms was tried: the uniform branch per store cost 1.1 ms per step)
+template <class V> __device__ __forceinline__ void stream_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st8(float* p, const f32x4& a, const f32x4& b) {
+  stream_store(a, reinterpret_cast<f32x4*>(p));
+  stream_store(b, reinterpret_cast<f32x4*>(p + 4));
 }
-
+__device__ __forceinline__ void st8(bf16* p, const f32x4& a, const f32x4& b) {
+  stream_store(bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]}, reinterpret_cast<bf16x8*>(p));
+}
 __device__ __forceinline__ void glds16(const bf16* src, char* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
@@ -120,6 +127,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
     if (HAS_BIAS) pbias = bias + n0 + lane;
   };
   auto issue = [&]() {
+#ifdef MAE_DBG_NO_DMA
+    return;
+#endif
     char* dst = smem + is_stage * STAGE + wave * (GPW * 1024);
     const int ko = is_k * BK2;
     glds16(p0 + ko, dst);
@@ -153,12 +163,20 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
 
   int ct = 0, ck = 0, cs = 0;
   bool prev_full = false;
+  // MUL / DGELU with a bf16 side input: the tile's (M,N) side input is fetched at the top of the tile's LAST K-step, so its
+  // HBM latency hides under that step's MFMAs instead of stalling every (j, mi) unit of the epilogue
+  constexpr bool PREF = (MODE == MAE_EPI_MUL || MODE == MAE_EPI_DGELU) && sizeof(TO) == 2;
+  bf16x8 qa[PREF ? NI / 2 : 1][PREF ? MI : 1];
   const int gb = (fq & 1) ? 3 + fq : fq;
   for (int step = 0; step < nsteps; ++step) {
     // ---- wait for this step's DMAs: allowed outstanding = vector-memory ops issued after them
     //      = the next AHEAD-1 steps' DMAs (+ the bias DMAs when that step opens a tile)
     //        (+ the previous tile's epilogue stores, when that tile was full so every store was issued)
     const bool after_epi = ct > 0 && prev_full && ck < AHEAD;
+#ifdef MAE_DBG_NO_DMA
+    if (false) {
+    } else
+#endif
     if (AHEAD == 2) {
       if (step + 1 >= nsteps) wait_vm<0>();
       else if (ck == nk - 1) wait_vm<GPW + NB>();   // the next step is a tile's first: it carried the bias DMAs
@@ -170,9 +188,23 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (PREF && ck == nk - 1) {
+      const int t = vb + ct * G;
+      const int64_t m0 = (int64_t)(t / tiles_n) * BM2;
+      const int n0 = (t % tiles_n) * BN;
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        int64_t m = m0 + wm * WROWS + mi * 16 + fr;
+        m = m < M ? m : M - 1;
+        const bf16* q = reinterpret_cast<const bf16*>(aux) + m * N + n0 + wn * (NI * 16) + 4 * gb;
+#pragma unroll
+        for (int j = 0; j < NI / 2; ++j) qa[PREF ? j : 0][PREF ? mi : 0] = *reinterpret_cast<const bf16x8*>(q + 32 * j);
+      }
+    }
     const char* a_base = smem + cs * STAGE + (wm * WROWS + fr) * 128;
     const char* b_base = smem + cs * STAGE + BM2 * 128 + (wn * (NI * 16) + fr) * 128;
     // fragments of both 32-deep halves are read up front, the DMA refill is issued between the two read bursts
+#ifndef MAE_DBG_NO_MFMA
     bf16x8 af[2][MI], bfr[2][NI];
     const int sw0 = ((0 + fq) ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
 #pragma unroll
@@ -191,6 +223,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][ni], af[ks][mi], acc[mi][ni], 0, 0, 0);
+#else
+    if (step + AHEAD < nsteps) issue();
+#endif
     cs = cs == NSTAGE - 1 ? 0 : cs + 1;
 
     if (++ck == nk) {
@@ -217,7 +252,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
           const int64_t m = m0 + wm * WROWS + mi * 16 + fr;
+#ifdef MAE_DBG_NO_EPI
+          if (m < M && acc[mi][2 * j][0] == 1.2345e30f) {
+#else
           if (m < M) {
+#endif
             const int64_t o = m * N + n0 + wn * (NI * 16) + nl;
             f32x4 v0 = acc[mi][2 * j] + b0, v1 = acc[mi][2 * j + 1] + b1;
             if (MODE == MAE_EPI_GELU) {
@@ -226,9 +265,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
               for (int r = 0; r < 4; ++r) {
                 v0[r] = to_f(from_f<TO>(v0[r]));
                 v1[r] = to_f(from_f<TO>(v1[r]));
-                a0[r] = gelu_fast(v0[r]);
-                a1[r] = gelu_fast(v1[r]);
               }
+              { f32x4 g_; gelu_fast_pair(v0, a0, g_); gelu_fast_pair(v1, a1, g_); }
               st8(out + o, v0, v1);
               st8(out2 + o, a0, a1);
             } else if (MODE == MAE_EPI_RESID) {
@@ -237,25 +275,25 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
               st8(out + o, v0, v1);
             } else if (MODE == MAE_EPI_DGELU) {
               f32x4 q0, q1;
-              ld8(reinterpret_cast<const TO*>(aux) + o, q0, q1);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                v0[r] *= gelu_grad_fast(q0[r]);
-                v1[r] *= gelu_grad_fast(q1[r]);
-              }
+              if (PREF) unpack8(qa[PREF ? j : 0][PREF ? mi : 0], q0, q1);
+              else ld8(reinterpret_cast<const TO*>(aux) + o, q0, q1);
+              { f32x4 a_, g_; gelu_fast_pair(q0, a_, g_); v0 *= g_; gelu_fast_pair(q1, a_, g_); v1 *= g_; }
               st8(out + o, v0, v1);
             } else if (MODE == MAE_EPI_GELU_GRAD) {
               f32x4 a0, a1, g0, g1;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                { float _a, _g; gelu_fast_pair(to_f(from_f<TO>(v0[r])), _a, _g); a0[r] = _a; g0[r] = _g; }
-                { float _a, _g; gelu_fast_pair(to_f(from_f<TO>(v1[r])), _a, _g); a1[r] = _a; g1[r] = _g; }
+                v0[r] = to_f(from_f<TO>(v0[r]));
+                v1[r] = to_f(from_f<TO>(v1[r]));
               }
+              gelu_fast_pair(v0, a0, g0);
+              gelu_fast_pair(v1, a1, g1);
               st8(out + o, g0, g1);
               st8(out2 + o, a0, a1);
             } else if (MODE == MAE_EPI_MUL) {
               f32x4 q0, q1;
-              ld8(reinterpret_cast<const TO*>(aux) + o, q0, q1);
+              if (PREF) unpack8(qa[PREF ? j : 0][PREF ? mi : 0], q0, q1);
+              else ld8(reinterpret_cast<const TO*>(aux) + o, q0, q1);
               st8(out + o, v0 * q0, v1 * q1);
             } else {
               st8(out + o, v0, v1);

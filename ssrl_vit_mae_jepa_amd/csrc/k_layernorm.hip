@@ -4,6 +4,20 @@
 // instantiate it (norm1/norm2/norm/decoder_norm), computed in fp32 (autocast keeps layer_norm in fp32).
 #include "kernels.h"
 
+#ifndef MAE_LN_NT
+#define MAE_LN_NT 1  // bit 0: fp32 residual-stream / dx stores stream (measured -0.4 ms per step); bit 1: the bf16 operand copies too (no gain)
+#endif
+#if MAE_LN_NT & 1
+#define LN_ST_A store4_nt
+#else
+#define LN_ST_A store4
+#endif
+#if MAE_LN_NT & 2
+#define LN_ST_B store4_nt
+#else
+#define LN_ST_B store4
+#endif
+
 namespace mae {
 
 // NV = float4 vectors per lane: covers dim <= 256*NV
@@ -30,7 +44,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
         v[i] = load4(px + c * 4);
         if (ADD) {
           v[i] += load4(branch + src * dim + c * 4);
-          store4(x_out + src * dim + c * 4, v[i]);
+          LN_ST_A(x_out + src * dim + c * 4, v[i]);
         }
         sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
       } else {
@@ -55,7 +69,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
       const int c = lane + 64 * i;
       if (c < D4) {
         const f32x4 o = (v[i] - mean) * rstd * load4(gamma + c * 4) + load4(beta + c * 4);
-        store4(py + c * 4, o);
+        LN_ST_B(py + c * 4, o);
       }
     }
     if (lane == 0) {
@@ -133,8 +147,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
         f32x4 d = (g[i] - s1 - xh[i] * s2) * rs;
         float* pd = dx_io + src * dim + c * 4;
         if (accumulate) d += load4(pd);
-        store4(pd, d);
-        if (dx_copy) store4(dx_copy + src * dim + c * 4, d);
+        LN_ST_A(pd, d);
+        if (dx_copy) LN_ST_B(dx_copy + src * dim + c * 4, d);
       }
     }
   }

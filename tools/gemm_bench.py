@@ -33,7 +33,38 @@ SHAPES = [  # name, M, N, K, epilogue, out dtype
     ("probe fc1 none", 72000, 1536, 384, "none", BF16),
     ("probe K=4096", 32768, 1152, 4096, "none", BF16),
 ]
+WGRAD_SHAPES = [  # name, M, N, K   (dW[N,K] = dY[M,N]^T A[M,K], db = colsum dY)
+    ("enc qkv wgrad", 72000, 1152, 384), ("enc proj wgrad", 72000, 384, 384), ("enc fc1 wgrad", 72000, 1536, 384),
+    ("enc fc2 wgrad", 72000, 384, 1536), ("dec qkv wgrad", 290000, 576, 192), ("dec proj wgrad", 290000, 192, 192),
+    ("dec fc1 wgrad", 290000, 768, 192), ("dec fc2 wgrad", 290000, 192, 768), ("patch wgrad", 70000, 384, 192),
+    ("dec embed wgrad", 72000, 192, 384), ("pred wgrad", 218000, 192, 192),
+]
 MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5}
+
+
+def wgrad_main(args, dev):
+    g = torch.Generator(device=dev).manual_seed(1)
+    for name, M, N, K in WGRAD_SHAPES:
+        if args.only and args.only not in name:
+            continue
+        dY = (torch.rand(M, N, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+        dW = torch.empty(N, K, device=dev)
+        db = torch.empty(N, device=dev)
+        scratch = torch.empty(max(1, lib.mae_linear_wgrad_scratch_bytes(M, N, K)), dtype=torch.uint8, device=dev)
+
+        def run():
+            check(lib.mae_linear_wgrad(_ptr(dY), _ptr(A), M, N, K, BF16, _ptr(dW), _ptr(db), _ptr(scratch), stream(dev)))
+        run()
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(args.rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(); e1.record(); torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e3)
+        t = sorted(times)[len(times) // 2]
+        nbytes = M * (N + K) * 2 + N * K * 4
+        print(f"{name:18s} M={M} N={N} K={K} | {t:7.1f} us {2 * M * N * K / t / 1e6:6.0f} TF/s {nbytes / t / 1e3:5.0f} GB/s (operands once) scratch {scratch.numel() / 1e6:.1f} MB", flush=True)
 
 
 def main():
@@ -41,8 +72,11 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--variants", default="v1,v2")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient GEMM (+ slab reduce) instead")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.wgrad:
+        return wgrad_main(args, dev)
     variants = args.variants.split(",")
     g = torch.Generator(device=dev).manual_seed(1)
     for name, M, N, K, epi, odt in SHAPES:
