@@ -12,6 +12,12 @@
 // Reference behaviour: F.scaled_dot_product_attention inside timm Attention.forward (no mask, no dropout).
 #include "gemm_mfma.h"
 
+#ifdef MAE_ATT_NT
+#define AT_ST store4_nt
+#else
+#define AT_ST store4
+#endif
+
 namespace mae {
 
 namespace {
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restri
     if (tq < T) {
       bf16* po = out + ((int64_t)b * T + tq) * H * HD + h * HD + 4 * g;
 #pragma unroll
-      for (int dt = 0; dt < AT<HD>::NDT; ++dt) store4(po + dt * 16, oacc[dt] * inv);
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt) AT_ST(po + dt * 16, oacc[dt] * inv);
       if (g == 0) lse[((int64_t)b * H + h) * T + tq] = m * scale + __logf(lsum);
     }
   }
@@ -261,7 +267,7 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
     const int tq = qt * 16 + i;
     if (tq < T) {
 #pragma unroll
-      for (int dt = 0; dt < AT<HD>::NDT; ++dt) store4(dbase + tq * gs + dt * 16 + 4 * g, dq[dt] * scale);
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt) AT_ST(dbase + tq * gs + dt * 16 + 4 * g, dq[dt] * scale);
     }
   }
 
@@ -308,8 +314,8 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
     if (tj < T) {
 #pragma unroll
       for (int dt = 0; dt < AT<HD>::NDT; ++dt) {
-        store4(dbase + tj * gs + os + dt * 16 + 4 * g, dk[dt] * scale);
-        store4(dbase + tj * gs + 2 * os + dt * 16 + 4 * g, dv[dt]);
+        AT_ST(dbase + tj * gs + os + dt * 16 + 4 * g, dk[dt] * scale);
+        AT_ST(dbase + tj * gs + 2 * os + dt * 16 + 4 * g, dv[dt]);
       }
     }
   }

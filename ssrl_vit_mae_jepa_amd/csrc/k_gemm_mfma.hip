@@ -361,13 +361,245 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
   }
 }
 
-// ordered (deterministic) sum of the per-split slabs: [S][N*K weight partials | N bias partials]
+// ---------------------------------------------------------------------------------------------------
+// wgrad v2: the same contraction on 192 x 192 tiles with an LDS-DMA ring (no register staging, no ds_write).
+//
+//   block = 512 threads = 8 waves as 4 (n) x 2 (k), wave tile 48 (n) x 96 (k): NI = 3, KI = 6 MFMA tiles, 72 accumulators
+//   stage = 64 reduction rows of X[:, k0:k0+192] then of dY[:, n0:n0+192], 384 B per row, 48 KiB; 3 stages, two K-steps of
+//           DMA in flight behind the compute (waves 0-3 fetch X, waves 4-7 fetch dY, 6 x 1 KiB global_load_lds each)
+//   LDS image: rows are NOT padded (the DMA writes 1 KiB runs); instead the 32-byte granule g of row r sits at
+//           g ^ ((r >> 1) & 3).  A 32-lane half of ds_read_b64_tr_b16 takes 8 consecutive rows x 32 B: rows of equal
+//           parity differ in (r >> 1) & 3, so they land in 4 different granules of one aligned 128-B group, and odd rows
+//           are 32 banks away from even rows (384-B row stride) -> all 64 banks, conflict-free.  The swizzle is applied
+//           on the DMA SOURCE address (the LDS destination of a DMA is lane-linear).
+//   Every Linear of the ViT-S/8 and YAML-decoder shapes has N and K multiples of 192; other shapes use gemm_tn_kernel.
+//   Staged bytes per flop are 0.65x those of the 128 x 128 register-staged kernel, and the ds_write_b128 traffic
+//   (79 B/clk, the v1 limiter together with the transposed reads) is gone.
+// ---------------------------------------------------------------------------------------------------
+constexpr int T2 = 192, T2_BR = 64, T2_RS = T2 * 2, T2_HALF = T2_BR * T2_RS, T2_STAGE = 2 * T2_HALF, T2_NSTAGE = 3;
+constexpr int T2_GPW = 6, T2_NI = 3, T2_KI = 6, T2_CPR = T2_RS / 16;  // 24 16-byte chunks per row
+
+__device__ __forceinline__ void tn_glds16(const bf16* src, char* dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+template <int N_>
+__device__ __forceinline__ void tn_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_tn2_kernel(const bf16* __restrict__ dY, const bf16* __restrict__ X, int64_t M, int N, int K,
+                                                          float* __restrict__ out, float* __restrict__ db, int64_t split_stride,
+                                                          int tiles_n, int tiles_k, int64_t m_chunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int vb = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = vb % (tiles_n * tiles_k);
+  const int split = vb / (tiles_n * tiles_k);
+  const int n0 = (tile / tiles_k) * T2, k0 = (tile % tiles_k) * T2;
+  const int64_t mbeg = (int64_t)split * m_chunk;
+  const int64_t mend = mbeg + m_chunk < M ? mbeg + m_chunk : M;
+  const int nsteps = mend > mbeg ? (int)((mend - mbeg + T2_BR - 1) / T2_BR) : 0;
+  const int last_valid = nsteps ? (int)(mend - mbeg - (int64_t)(nsteps - 1) * T2_BR) : 0;  // rows of the last step (1..64)
+
+  // ---- producer: this wave's 6 DMA instructions of a stage; lane -> (row, 16-byte slot) of the operand's 64 x 24 chunks
+  const bool isY = wave >= 4;
+  const bf16* gbase = isY ? dY + n0 : X + k0;
+  const int64_t ld = isY ? N : K;
+  int row_[T2_GPW], sc_[T2_GPW];
+#pragma unroll
+  for (int q = 0; q < T2_GPW; ++q) {
+    const int c = ((wave & 3) * T2_GPW + q) * 64 + lane;
+    const int row = c / T2_CPR, slot = c % T2_CPR;
+    row_[q] = row;
+    sc_[q] = ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1)) * 8;  // source element offset of the chunk stored in `slot`
+  }
+  const bf16 *p0 = gbase + (mbeg + row_[0]) * ld + sc_[0], *p1 = gbase + (mbeg + row_[1]) * ld + sc_[1],
+             *p2 = gbase + (mbeg + row_[2]) * ld + sc_[2], *p3 = gbase + (mbeg + row_[3]) * ld + sc_[3],
+             *p4 = gbase + (mbeg + row_[4]) * ld + sc_[4], *p5 = gbase + (mbeg + row_[5]) * ld + sc_[5];
+  const int64_t inc = (int64_t)T2_BR * ld;
+  int is_step = 0, is_stage = 0;
+  auto issue = [&]() {
+#ifdef MAE_DBG_TN_NO_LOAD
+    return;
+#endif
+    char* dst = smem + is_stage * T2_STAGE + (isY ? T2_HALF : 0) + (wave & 3) * (T2_GPW * 1024);
+    if (is_step == nsteps - 1 && last_valid < T2_BR) {
+      // ragged last step: rows past the chunk are fetched from its last valid row (finite data, in bounds); the dY rows
+      // among them are zeroed in LDS before use, which also removes their X rows from the product
+      const int64_t mb = mbeg + (int64_t)is_step * T2_BR;
+#pragma unroll
+      for (int q = 0; q < T2_GPW; ++q) {
+        const int64_t m = mb + (row_[q] < last_valid ? row_[q] : last_valid - 1);
+        tn_glds16(gbase + m * ld + sc_[q], dst + q * 1024);
+      }
+    } else {
+      tn_glds16(p0, dst); tn_glds16(p1, dst + 1024); tn_glds16(p2, dst + 2048);
+      tn_glds16(p3, dst + 3072); tn_glds16(p4, dst + 4096); tn_glds16(p5, dst + 5120);
+      p0 += inc; p1 += inc; p2 += inc; p3 += inc; p4 += inc; p5 += inc;
+    }
+    is_stage = is_stage == T2_NSTAGE - 1 ? 0 : is_stage + 1;
+    ++is_step;
+  };
+
+  f32x4 acc[T2_KI][T2_NI], accb[T2_NI];
+#pragma unroll
+  for (int i = 0; i < T2_KI; ++i)
+#pragma unroll
+    for (int j = 0; j < T2_NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < T2_NI; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = db != nullptr && k0 == 0 && wk == 0;
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
+
+  // ---- consumer: transposed-read addresses.  rows 4g + q (+16, +32), 8 bytes at column 4p of a 16-column tile
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p = lane & 3;
+  const int sw = ((g & 1) << 1) | (q4 >> 1);  // (row >> 1) & 3 of every row this lane reads
+  const int lane_off = (4 * g + q4) * T2_RS + p * 8;
+  int yo[T2_NI], xo[T2_KI];
+#pragma unroll
+  for (int ni = 0; ni < T2_NI; ++ni) yo[ni] = T2_HALF + lane_off + (((wn * T2_NI + ni) ^ sw) * 32);
+#pragma unroll
+  for (int ki = 0; ki < T2_KI; ++ki) xo[ki] = lane_off + (((wk * T2_KI + ki) ^ sw) * 32);
+
+  bf16x8 yf[2][T2_NI], xf[2][T2_KI];
+#define TN2_READ_FRAGS(sb)                                                                              \
+  {                                                                                                     \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                     \
+      _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni) {                                            \
+        const bf16x4 lo = lds_read_tr((sb) + yo[ni] + (32 * h) * T2_RS);                                \
+        const bf16x4 hi = lds_read_tr((sb) + yo[ni] + (32 * h + 16) * T2_RS);                           \
+        yf[h][ni] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                     \
+      }                                                                                                 \
+      _Pragma("unroll") for (int ki = 0; ki < T2_KI; ++ki) {                                            \
+        const bf16x4 lo = lds_read_tr((sb) + xo[ki] + (32 * h) * T2_RS);                                \
+        const bf16x4 hi = lds_read_tr((sb) + xo[ki] + (32 * h + 16) * T2_RS);                           \
+        xf[h][ki] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                     \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+#if defined(MAE_DBG_TN_SLEEP)
+#define TN2_MFMA() { __builtin_amdgcn_s_sleep(10); }
+#elif defined(MAE_DBG_TN_NO_MFMA)
+#define TN2_MFMA() {}
+#else
+#define TN2_MFMA()                                                                                      \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                  \
+      _Pragma("unroll") for (int ki = 0; ki < T2_KI; ++ki)                                              \
+        _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                            \
+          acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[ks][ki], yf[ks][ni], acc[ki][ni], 0, 0, 0); \
+      if (do_bias) {                                                                                    \
+        _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                            \
+          accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[ks][ni], accb[ni], 0, 0, 0);      \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+#endif
+  // Ping-pong: waves 0-3 (group A) and 4-7 (group B) sit pairwise on the same SIMDs.  Between the two barriers of a step
+  // A reads its fragments of step st while B runs the MFMAs of step st-1; after the second barrier A runs the MFMAs of
+  // step st while B reads.  The LDS latency burst that follows a barrier is thus always covered by the other group's
+  // MFMAs (one barrier per step with both groups in phase left the MFMA pipe idle ~55 % of the time).
+  const bool grpB = wave >= 4;
+  if (nsteps > 0) issue();
+  if (nsteps > 1) issue();
+  int cs = 0;
+#define TN2_STEP_HEAD()                                                                                 \
+    if (st + 1 < nsteps) tn_wait_vm<T2_GPW>(); else tn_wait_vm<0>();                                    \
+    __builtin_amdgcn_s_barrier();                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    asm volatile("" ::: "memory");                                                                      \
+    const char* sb = smem + cs * T2_STAGE;                                                              \
+    if (st == nsteps - 1 && last_valid < T2_BR) {                                                       \
+      for (int i = tid; i < (T2_BR - last_valid) * T2_CPR; i += 512)                                    \
+        *reinterpret_cast<uint4*>(smem + cs * T2_STAGE + T2_HALF + (last_valid + i / T2_CPR) * T2_RS + (i % T2_CPR) * 16) = uint4{0, 0, 0, 0}; \
+      __syncthreads();                                                                                  \
+    }                                                                                                   \
+    if (st + 2 < nsteps) issue(); /* refills the stage group B finished reading before this step's first barrier */
+#define TN2_STEP_MID()                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    __builtin_amdgcn_s_barrier();                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    asm volatile("" ::: "memory");
+  // the two groups run separate copies of the loop (no control-flow merges between them: merged, the fragment registers
+  // of the two schedules were kept apart by copies and the kernel spilled)
+  if (!grpB) {
+    for (int st = 0; st < nsteps; ++st) {
+      TN2_STEP_HEAD()
+      TN2_READ_FRAGS(sb)
+      TN2_STEP_MID()
+      TN2_MFMA()
+      __builtin_amdgcn_sched_barrier(0);
+      cs = cs == T2_NSTAGE - 1 ? 0 : cs + 1;
+    }
+  } else {
+    for (int st = 0; st < nsteps; ++st) {
+      TN2_STEP_HEAD()
+      if (st > 0) TN2_MFMA()
+      TN2_STEP_MID()
+      TN2_READ_FRAGS(sb)
+      __builtin_amdgcn_sched_barrier(0);
+      cs = cs == T2_NSTAGE - 1 ? 0 : cs + 1;
+    }
+    if (nsteps > 0) TN2_MFMA()
+  }
+#undef TN2_STEP_HEAD
+#undef TN2_STEP_MID
+#undef TN2_READ_FRAGS
+#undef TN2_MFMA
+  // D[i = k][j = n]: lane holds n = tile col (lane & 15), k = 4 * (lane >> 4) + r -> 16-byte store along k
+  float* o = out + (int64_t)split * split_stride;
+  if (do_bias && lane < 16) {
+#pragma unroll
+    for (int ni = 0; ni < T2_NI; ++ni) db[(int64_t)split * split_stride + n0 + wn * (T2_NI * 16) + ni * 16 + lane] = accb[ni][0];
+  }
+#pragma unroll
+  for (int ni = 0; ni < T2_NI; ++ni) {
+    const int n = n0 + wn * (T2_NI * 16) + ni * 16 + (lane & 15);
+#pragma unroll
+    for (int ki = 0; ki < T2_KI; ++ki) {
+      const int k = k0 + wk * (T2_KI * 16) + ki * 16 + (lane >> 4) * 4;
+      store4(o + (int64_t)n * K + k, acc[ki][ni]);
+    }
+  }
+}
+
+static bool wgrad2_ok(int64_t M, int N, int K) {
+  static const bool off = [] { const char* v = getenv("MAE_WGRAD"); return v && v[0] == 'v' && v[1] == '1'; }();
+  return !off && N % T2 == 0 && K % T2 == 0 && M >= 4096;
+}
+static int wgrad2_splits(int64_t M, int N, int K) {
+  const int64_t tiles = (int64_t)(N / T2) * (K / T2);
+  int64_t S = std::max<int64_t>(1, 256 / tiles);                  // one block per CU (144 KiB of LDS)
+  S = std::min<int64_t>(S, std::max<int64_t>(1, M / 256));        // at least 4 reduction steps per block
+  return (int)S;
+}
+
+// ordered (deterministic) sum of the per-split slabs: [S][N*K weight partials | N bias partials].
+// 256 threads = 32 outputs (float4) x 8 slices of the split index; slice sl adds slabs sl, sl+8, ... and the 8 partial
+// sums are combined through LDS in slice order, so the result does not depend on the grid.  (One thread per output
+// walking all S slabs serially took 10 us per launch at S = 56 and dominated the small-tile wgrads.)
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t stride4, int64_t nw4,
                                                           int64_t nb4, float* __restrict__ dW, float* __restrict__ db) {
-  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nw4 + nb4; i += (int64_t)gridDim.x * 256) {
-    f32x4 acc = load4(slabs + i * 4);
-    for (int s = 1; s < S; ++s) acc += load4(slabs + ((int64_t)s * stride4 + i) * 4);
-    if (i < nw4) store4(dW + i * 4, acc); else store4(db + (i - nw4) * 4, acc);
+  __shared__ f32x4 red[8][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t total = nw4 + nb4;
+  for (int64_t base = blockIdx.x * 32ll; base < total; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + o;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (i < total)
+      for (int s = sl; s < S; s += 8) acc += load4(slabs + ((int64_t)s * stride4 + i) * 4);
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      f32x4 t = red[0][o];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += red[k][o];
+      if (i < nw4) store4(dW + i * 4, t); else store4(db + (i - nw4) * 4, t);
+    }
+    __syncthreads();
   }
 }
 
@@ -381,7 +613,8 @@ static int wgrad_splits(int64_t M, int N, int K) {
 
 int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K) {
   if (N % 64 != 0 || K % 64 != 0) return 0;
-  const int S = wgrad_splits(M, N, K);
+  int S = wgrad_splits(M, N, K);
+  if (N % T2 == 0 && K % T2 == 0) S = std::max(S, wgrad2_splits(M, N, K));
   return S > 1 ? round_up((int64_t)S * ((int64_t)N * K + N) * 4, 256) : 0;
 }
 
@@ -400,7 +633,8 @@ static int launch_tn(const bf16* dY, const bf16* X, int64_t M, int N, int K, flo
 int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* dW, float* db, void* slab, hipStream_t s) {
   if (N % 64 != 0 || K % 64 != 0 || M < 1) return MFMA_UNSUPPORTED;
   if ((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)db | (uintptr_t)slab) & 15) != 0) return MFMA_UNSUPPORTED;
-  const int S = wgrad_splits(M, N, K);
+  const bool v2 = wgrad2_ok(M, N, K);
+  const int S = v2 ? wgrad2_splits(M, N, K) : wgrad_splits(M, N, K);
   if (S > 1 && !slab) return MFMA_UNSUPPORTED;
   const int64_t m_chunk = round_up(cdiv(M, S), 64);
   const int64_t stride = S > 1 ? (int64_t)N * K + N : 0;
@@ -408,14 +642,21 @@ int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, fl
   float* dbo = !db ? nullptr : (S > 1 ? out + (int64_t)N * K : db);
   const bool n128 = N % 128 == 0, k128 = K % 128 == 0;
   int r;
-  if (n128 && k128) r = launch_tn<4, 4>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
+  if (v2) {
+    const int tiles_n = N / T2, tiles_k = K / T2;
+    const int lds = T2_NSTAGE * T2_STAGE;
+    MAE_HIP(hipFuncSetAttribute((const void*)gemm_tn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(gemm_tn2_kernel, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(512), lds, s, dY, X, M, N, K, out, dbo, stride, tiles_n, tiles_k, m_chunk);
+    MAE_LAUNCH_CHECK();
+    r = 0;
+  } else if (n128 && k128) r = launch_tn<4, 4>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
   else if (n128) r = launch_tn<4, 2>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
   else if (k128) r = launch_tn<2, 4>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
   else r = launch_tn<2, 2>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
   if (r) return r;
   if (S > 1) {
     const int64_t nw4 = (int64_t)N * K / 4, nb4 = db ? N / 4 : 0;
-    const int grid = (int)std::min<int64_t>(cdiv(nw4 + nb4, 256), 2048);
+    const int grid = (int)std::min<int64_t>(cdiv(nw4 + nb4, 32), 4096);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)slab, S, stride / 4, nw4, nb4, dW, db);
     MAE_LAUNCH_CHECK();
   }

@@ -208,7 +208,7 @@ def test_linear_fwd(dev, M, N, K, dt, epi):
         assert rel_err(out2.float(), F.gelu((acc + bias.double()).to(TDT[odt]).double())) < (2e-5 if odt == F32 else 5e-3)
 
 
-@pytest.mark.parametrize("M,N,K", [(70, 144, 192), (5000, 432, 144), (4100, 192, 768), (9000, 384, 384), (300, 16, 32), (8200, 1536, 384), (6000, 384, 1536)])
+@pytest.mark.parametrize("M,N,K", [(70, 144, 192), (5000, 432, 144), (4100, 192, 768), (9000, 384, 384), (300, 16, 32), (8200, 1536, 384), (6000, 384, 1536), (4289, 576, 192), (20000, 1152, 384), (4096, 192, 192)])
 @pytest.mark.parametrize("dt", [F32, BF16])
 def test_linear_wgrad(dev, M, N, K, dt):
     g = G(M + N + K)
