@@ -109,6 +109,9 @@ YAML_TINY = MAEConfig(image_size=96, patch_size=8, in_chans=3, embed_dim=144, de
                       decoder_embed_dim=192, decoder_depth=2, decoder_num_heads=6)
 VIT_S8_YAMLDEC = MAEConfig(image_size=96, patch_size=8, in_chans=3, embed_dim=384, depth=12, num_heads=6,
                            decoder_embed_dim=192, decoder_depth=2, decoder_num_heads=6)
+# the code-default decoder width / depth (src/models/mae.py:49-50) with a valid head count
+VIT_S8_DEC512 = MAEConfig(image_size=96, patch_size=8, in_chans=3, embed_dim=384, depth=12, num_heads=6,
+                          decoder_embed_dim=512, decoder_depth=4, decoder_num_heads=8)
 
 
 # ----------------------------------------------------------------------------

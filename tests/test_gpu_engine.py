@@ -305,6 +305,24 @@ def test_vits8_fp32_matches_oracle(dev):
     assert (num / den) ** 0.5 < 2e-4
 
 
+# the code-default decoder (512 wide, 4 deep) with 8 heads: head dim 64, 145 tokens -> the
+# 5-chunk attention kernels, K = 512 / 2048 GEMMs, 192-multiple wgrad tiles not available (512 % 192 != 0)
+@pytest.mark.parametrize("prec,B,tol_loss,tol_grad", [("bf16", 3, 5e-3, 5e-2), ("fp32", 2, 1e-4, 2e-4)])
+def test_vits8_dec512_matches_oracle(dev, prec, B, tol_loss, tol_grad):
+    cfg, r = O.VIT_S8_DEC512, 0.75
+    model, params = build(cfg, prec, dev, r)
+    images = O.synthetic_images(B, cfg)
+    noise = O.make_noise(B, cfg.sequence_length, torch.Generator().manual_seed(9))
+    loss_ref, grads_ref, aux = O.loss_and_grads(params, cfg, images, noise, r, bf16=(prec == "bf16"))
+    loss, keep, mask = model.loss_and_grads(images.to(dev), noise.to(dev), return_indices=True)
+    assert torch.equal(keep.cpu(), aux["idx_keep"]) and torch.equal(mask.cpu(), aux["idx_mask"])
+    assert abs(loss.item() - loss_ref.item()) <= tol_loss * abs(loss_ref.item())
+    g = model.named_flat_views(model.flat_grads)
+    num = sum(float((g[n].double().cpu() - gr.double()).pow(2).sum()) for n, gr in grads_ref.items())
+    den = sum(float(gr.double().pow(2).sum()) for gr in grads_ref.values())
+    assert (num / den) ** 0.5 < tol_grad
+
+
 def test_step_is_hip_graph_capturable(dev):
     """The engine only enqueues on the caller's stream (no allocation, no sync): after one eager call (lazy attribute
     setup) a whole step can be captured into a graph and replayed with the same bits."""

@@ -21,6 +21,9 @@ def test_vits8_census_and_flops_match_baseline_md():
     assert c["total"] == 22_454_016 and c["frozen"] == 83_520 and c["trainable"] == 22_370_496
     assert abs(O.flops_per_image_step(O.VIT_S8_YAMLDEC) / 1e9 - 5.5803) < 1e-4
     assert abs(O.flops_per_image_step(O.YAML_TINY) / 1e9 - 1.1264) < 1e-4
+    c = O.param_census(O.VIT_S8_DEC512)
+    assert c["total"] == 34_405_824 and c["trainable"] == 34_275_904
+    assert abs(O.flops_per_image_step(O.VIT_S8_DEC512) / 1e9 - 16.2442) < 1e-4
 
 
 def test_state_dict_names_follow_survey_8b():
