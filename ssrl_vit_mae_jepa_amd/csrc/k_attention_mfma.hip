@@ -99,8 +99,13 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // NCH > 0: the number of 32-token chunks is a compile-time constant, the chunk loops are fully unrolled and the
 // compiler overlaps the MFMA / exp chains of different chunks (a runtime loop serialises them); NCH == 0: any length.
+// Threads per block: one wave per 16-token tile while the variant's registers allow 4 waves per SIMD (<= 128 VGPRs);
+// the wide unrolled variants keep 8 waves and walk their tiles in passes.
+template <int HD> struct FwdCap { static constexpr int v = 512; };  // (10 waves for the 145-token decoder forward measured 12 % slower than 5 waves x 2 passes)
+template <int NCH> struct BwdCap { static constexpr int v = NCH == 0 ? 1024 : 512; };
+
 template <int HD, int NCH>
-__global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
+__global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
                                                             bf16* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
@@ -177,7 +182,7 @@ __global__ void __launch_bounds__(512) attn_fwd_mfma_kernel(const bf16* __restri
 }
 
 template <int HD, int NCH>
-__global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+__global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
                                                             int Tp, int H, float scale, bf16* __restrict__ d_qkv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -321,10 +326,10 @@ __global__ void __launch_bounds__(512) attn_bwd_mfma_kernel(const bf16* __restri
   }
 }
 
-static int attn_waves(int T) {
-  const int nt = (T + 15) / 16;
-  const int passes = (nt + 7) / 8;
-  return (nt + passes - 1) / passes;  // <= 8 waves, balanced over the 16-token tiles
+static int attn_waves(int T, int max_threads) {
+  const int nt = (T + 15) / 16, maxw = max_threads / 64;
+  const int passes = (nt + maxw - 1) / maxw;
+  return (nt + passes - 1) / passes;  // <= maxw waves, balanced over the 16-token tiles
 }
 
 static bool attn_supported(int T, int H, int hd) {
@@ -335,7 +340,7 @@ template <int HD, int NCH>
 static int launch_attn_fwd(const bf16* qkv, int B, int T, int Tp, int H, size_t lds, float scale, bf16* out, float* lse, hipStream_t s) {
   auto kern = attn_fwd_mfma_kernel<HD, NCH>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T)), lds, s, qkv, T, Tp, H, scale, out, lse);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, FwdCap<HD>::v)), lds, s, qkv, T, Tp, H, scale, out, lse);
   MAE_LAUNCH_CHECK();
   return 0;
 }
@@ -344,7 +349,7 @@ static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, 
                            float scale, bf16* d_qkv, hipStream_t s) {
   auto kern = attn_bwd_mfma_kernel<HD, NCH>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, BwdCap<NCH>::v)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv);
   MAE_LAUNCH_CHECK();
   return 0;
 }
