@@ -99,6 +99,17 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // NCH > 0: the number of 32-token chunks is a compile-time constant, the chunk loops are fully unrolled and the
 // compiler overlaps the MFMA / exp chains of different chunks (a runtime loop serialises them); NCH == 0: any length.
+// Every workgroup runs load (HBM) -> compute -> store, and the workgroups resident on the chip fall into step: all load,
+// then all compute (measured: the phases add up, e.g. decoder backward 155 us of staging + 330 us of compute = 483 us).
+// The first generation of workgroups is therefore started out of phase: the workgroup in residency slot r of its CU
+// (blockIdx / 256, one slot per CU filled first) waits r * stagger ticks of the 100 MHz wall clock before its loads.
+__device__ __forceinline__ void first_generation_stagger(int stagger, int gen1) {
+  if (stagger > 0 && (int)blockIdx.x >= 256 && (int)blockIdx.x < gen1) {
+    const uint64_t t0 = wall_clock64(), wait = (uint64_t)(blockIdx.x >> 8) * stagger;
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(4);
+  }
+}
+
 // Threads per block: one wave per 16-token tile while the variant's registers allow 4 waves per SIMD (<= 128 VGPRs);
 // the wide unrolled variants keep 8 waves and walk their tiles in passes.
 template <int HD> struct FwdCap { static constexpr int v = 512; };  // (10 waves for the 145-token decoder forward measured 12 % slower than 5 waves x 2 passes)
@@ -106,8 +117,9 @@ template <int NCH> struct BwdCap { static constexpr int v = NCH == 0 ? 1024 : 51
 
 template <int HD, int NCH>
 __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
-                                                            bf16* __restrict__ out, float* __restrict__ lse) {
+                                                            bf16* __restrict__ out, float* __restrict__ lse, int stagger, int gen1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  first_generation_stagger(stagger, gen1);
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
   char* sK = sQ + img;
@@ -143,21 +155,25 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
       }
       // lane: query i, keys j = c*32 + 4g + r (s0) and c*32 + 16 + 4g + r (s1)
       const int j0 = c * 32 + 4 * g;
-      float mc = -INFINITY;
+      if (NCH > 0 ? c == NCH - 1 : c * 32 + 32 > T) {  // only the last chunk holds keys past T (static when unrolled, else wave-uniform)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (j0 + r >= T) s0[r] = -INFINITY;
-        if (j0 + 16 + r >= T) s1[r] = -INFINITY;
-        mc = fmaxf(mc, fmaxf(s0[r], s1[r]));
+        for (int r = 0; r < 4; ++r) {
+          if (j0 + r >= T) s0[r] = -INFINITY;
+          if (j0 + 16 + r >= T) s1[r] = -INFINITY;
+        }
       }
+      float mc = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
       mc = group_max(mc);
       const float mn = fmaxf(m, mc);  // finite from chunk 0 on (key 0 is always valid)
-      const float alpha = exp2f((m - mn) * sl2);
+      // raw v_exp_f32 (arguments are <= 0; exp2(-inf) = 0): the library exp2f adds a denormal-range rescale
+      // (v_cmp + 2 v_cndmask + v_ldexp per element) that an attention probability does not need
+      const float mn2 = mn * sl2;
+      const float alpha = __builtin_amdgcn_exp2f(m * sl2 - mn2);
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s0[r] = exp2f((s0[r] - mn) * sl2);
-        s1[r] = exp2f((s1[r] - mn) * sl2);
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], sl2, -mn2));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], sl2, -mn2));
         ps += s0[r] + s1[r];
       }
       lsum = lsum * alpha + ps;
@@ -184,8 +200,9 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
 template <int HD, int NCH>
 __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
-                                                            int Tp, int H, float scale, bf16* __restrict__ d_qkv) {
+                                                            int Tp, int H, float scale, bf16* __restrict__ d_qkv, int stagger, int gen1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  first_generation_stagger(stagger, gen1);
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
   char* sK = sQ + img;
@@ -235,6 +252,9 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   const int nt16 = (T + 15) >> 4, nchunks = NCH > 0 ? NCH : (Tp >> 5);
 
   // ---- phase A: wave owns 16 queries; dQ^T[d][i] = sum_j K^T[d][j] dS^T[j][i]
+#ifdef MAE_DBG_ATT_NO_A
+  if (T < 0)
+#endif
   for (int qt = wave; qt < nt16; qt += nwaves) {
     bf16x8 qf[AT<HD>::NKS], dof[AT<HD>::NKS];
 #pragma unroll
@@ -257,10 +277,17 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
         p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sV, c * 32 + 16, ks, lane), dof[ks], p1, 0, 0, 0);
       }
       const int j0 = c * 32 + 4 * g;
+      if (NCH > 0 ? c == NCH - 1 : c * 32 + 32 > T) {  // only the last chunk holds keys past T (static when unrolled, else wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (j0 + r >= T) s0[r] = -INFINITY;
+          if (j0 + 16 + r >= T) s1[r] = -INFINITY;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pa = (j0 + r < T) ? exp2f(s0[r] * sl2 - li) : 0.f;
-        const float pb = (j0 + 16 + r < T) ? exp2f(s1[r] * sl2 - li) : 0.f;
+        const float pa = __builtin_amdgcn_exp2f(fmaf(s0[r], sl2, -li));  // raw v_exp_f32: exp2(-inf) = 0, no denormal rescale
+        const float pb = __builtin_amdgcn_exp2f(fmaf(s1[r], sl2, -li));
         s0[r] = pa * (p0[r] - Di);
         s1[r] = pb * (p1[r] - Di);
       }
@@ -277,6 +304,9 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   }
 
   // ---- phase B: wave owns 16 keys; dV^T[d][j] = sum_i dO^T[d][i] P[i][j], dK^T[d][j] = sum_i Q^T[d][i] dS[i][j]
+#ifdef MAE_DBG_ATT_NO_B
+  if (T < 0)
+#endif
   for (int jt = wave; jt < nt16; jt += nwaves) {
     bf16x8 kf[AT<HD>::NKS], vf[AT<HD>::NKS];
 #pragma unroll
@@ -303,8 +333,8 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
       f32x4 ds0, ds1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s0[r] = exp2f(s0[r] * sl2 - l0[r]);
-        s1[r] = exp2f(s1[r] * sl2 - l1[r]);
+        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], sl2, -l0[r]));
+        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], sl2, -l1[r]));
         ds0[r] = s0[r] * (p0[r] - D0[r]);
         ds1[r] = s1[r] * (p1[r] - D1[r]);
       }
@@ -332,6 +362,16 @@ static int attn_waves(int T, int max_threads) {
   return (nt + passes - 1) / passes;  // <= maxw waves, balanced over the 16-token tiles
 }
 
+static int attn_stagger() {
+  static const int v = [] { const char* e = getenv("MAE_ATT_STAGGER"); return e ? atoi(e) : 0; }();
+  return v;
+}
+// workgroups resident per CU (LDS and wave-slot limits; registers are covered by the launch bounds)
+static int attn_resident(size_t lds, int threads) {
+  const int by_lds = (int)((160 * 1024) / lds), by_waves = 32 / (threads / 64);
+  return std::max(1, std::min(std::min(by_lds, by_waves), 8));
+}
+
 static bool attn_supported(int T, int H, int hd) {
   return (hd == 32 || hd == 64) && T >= 1 && T <= 1024 && ((int64_t)H * hd) % 8 == 0;
 }
@@ -340,7 +380,7 @@ template <int HD, int NCH>
 static int launch_attn_fwd(const bf16* qkv, int B, int T, int Tp, int H, size_t lds, float scale, bf16* out, float* lse, hipStream_t s) {
   auto kern = attn_fwd_mfma_kernel<HD, NCH>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, FwdCap<HD>::v)), lds, s, qkv, T, Tp, H, scale, out, lse);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, FwdCap<HD>::v)), lds, s, qkv, T, Tp, H, scale, out, lse, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, FwdCap<HD>::v)));
   MAE_LAUNCH_CHECK();
   return 0;
 }
@@ -349,7 +389,7 @@ static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, 
                            float scale, bf16* d_qkv, hipStream_t s) {
   auto kern = attn_bwd_mfma_kernel<HD, NCH>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, BwdCap<NCH>::v)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, BwdCap<NCH>::v)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, BwdCap<NCH>::v)));
   MAE_LAUNCH_CHECK();
   return 0;
 }
