@@ -222,12 +222,47 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   stage_image_dma<HD>(sK, img, base + os, gs, T, wave, nwaves, lane);
   stage_image_dma<HD>(sV, img, base + 2 * os, gs, T, wave, nwaves, lane);
   stage_image_dma<HD>(sdO, img, dobase, os, T, wave, nwaves, lane);
+  // D_t = dO_t . O_t with CPR lanes per row (dO chunk from the staged image, O chunk from global), shuffle-reduced.
+  // The O chunks and the log-sum-exps are fetched into registers BEFORE the wait on the staging DMAs, so the two global
+  // round trips of a workgroup's prologue overlap instead of following each other (up to PF slots per thread; longer
+  // sequences take the plain loop).
+  constexpr int CPR = AT<HD>::CPR, PF = 4;
+  const int total = Tp * CPR;
+  const bool pf = total <= PF * (int)blockDim.x;
+  bf16x8 o_pf[PF];
+  float l_pf[PF];
+  if (pf) {
+#pragma unroll
+    for (int it = 0; it < PF; ++it) {
+      const int idx = it * blockDim.x + threadIdx.x;
+      const int t = idx / CPR, cc = idx - t * CPR;
+      const bool live = idx < total && t < T;
+      const int tc = live ? t : 0;
+      o_pf[it] = *reinterpret_cast<const bf16x8*>(obase + tc * os + (live ? cc : 0) * 8);
+      l_pf[it] = lse[((int64_t)b * H + h) * T + tc];
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  // D_t = dO_t . O_t with CPR lanes per row (dO chunk from the staged image, O chunk from global), shuffle-reduced
-  {
-    constexpr int CPR = AT<HD>::CPR;
-    const int total = Tp * CPR;
+  if (pf) {
+#pragma unroll
+    for (int it = 0; it < PF; ++it) {
+      const int idx = it * blockDim.x + threadIdx.x;
+      const int t = idx / CPR, cc = idx - t * CPR;
+      float D = 0.f;
+      if (idx < total && t < T) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sdO + t * AT<HD>::RS + cc * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) D = fmaf((float)a[e], (float)o_pf[it][e], D);
+      }
+#pragma unroll
+      for (int off = CPR / 2; off > 0; off >>= 1) D += __shfl_xor(D, off, 64);
+      if (idx < total && cc == 0) {
+        sD[t] = D;
+        sLse[t] = t < T ? l_pf[it] * kLog2e : 1e30f;
+      }
+    }
+  } else {
     for (int base = 0; base < total; base += blockDim.x) {
       const int idx = base + threadIdx.x;
       const int t = idx / CPR, cc = idx - t * CPR;

@@ -343,7 +343,8 @@ static bool prefer_bm192(int64_t M, int N) {
 
 template <int MODE, class TO>
 static int launch_nt2_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
-  if (N % 192 == 0) {
+  static const bool force_ni4 = [] { const char* v = getenv("MAE_NT_NI"); return v && atoi(v) == 4; }();
+  if (N % 192 == 0 && !(force_ni4 && N % 128 == 0)) {
     if (prefer_bm192(M, N)) return launch_nt2<MODE, TO, 6, 3>(A, W, M, N, K, e, s);
     return launch_nt2<MODE, TO, 6, 4>(A, W, M, N, K, e, s);
   }
