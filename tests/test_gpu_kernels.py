@@ -208,6 +208,28 @@ def test_linear_fwd(dev, M, N, K, dt, epi):
         assert rel_err(out2.float(), F.gelu((acc + bias.double()).to(TDT[odt]).double())) < (2e-5 if odt == F32 else 5e-3)
 
 
+# The deferred-epilogue kernel retires a tile's GELU epilogue inside the next tile's K-loop: it needs workgroups that own
+# several tiles (more than 256 tiles), a ragged last row of tiles, and every units-per-step schedule (K = 192 / 384 / 768).
+@pytest.mark.parametrize("M,N,K,has_bias", [(18020, 1536, 384, True), (40100, 768, 192, True), (17000, 512, 768, False), (66000, 128, 192, True)])
+def test_linear_fwd_gelu_grad_many_tiles(dev, M, N, K, has_bias):
+    g = G(M + N + K)
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16); W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g) if has_bias else None
+    Ad, Wd = A.to(dev), W.to(dev)
+    pre = (Ad.float() @ Wd.float().t()) + (bias.to(dev) if has_bias else 0.0)   # fp32 products of bf16 values, fp32 sum
+    pre = pre.to(torch.bfloat16).double()
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    out2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    check(lib.mae_linear_fwd(_ptr(Ad), _ptr(Wd), _ptr(dv(bias)) if has_bias else None, M, N, K, BF16, 4, BF16, _ptr(out), _ptr(out2), None, stream(dev)))
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any() and not torch.isnan(out2.float()).any()
+    # the reference pre-activation is rounded to bf16 from a differently-ordered fp32 sum: compare with a tolerance of a
+    # few bf16 ulps on the slope / value, and tightly in the mean
+    slope_ref, act_ref = _gelu_grad(pre), F.gelu(pre)
+    assert rel_err(out.double(), slope_ref) < 5e-3 and rel_err(out2.double(), act_ref) < 5e-3
+    assert (out.double() - slope_ref).abs().max() < 0.05 and (out2.double() - act_ref).abs().max() < 0.08
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 144, 192), (5000, 432, 144), (4100, 192, 768), (9000, 384, 384), (300, 16, 32), (8200, 1536, 384), (6000, 384, 1536), (4289, 576, 192), (20000, 1152, 384), (4096, 192, 192)])
 @pytest.mark.parametrize("dt", [F32, BF16])
 def test_linear_wgrad(dev, M, N, K, dt):
