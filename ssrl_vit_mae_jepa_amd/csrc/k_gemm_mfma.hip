@@ -40,7 +40,10 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int MODE, class TO, int NI>
+// RG ("ragged"): N and K only have to be multiples of 8 (16-byte rows): the last tile column and the last K-step are
+// zero-filled on load (predicated, nothing is read out of bounds) and the stores are guarded by column.  This is the
+// MFMA path of the reference's shipped tiny config (D = 144: K = 144 / 576, N = 432 / 144 / 576).
+template <int MODE, class TO, int NI, bool RG>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M,
                                                          int N, int K, EpiArgs ep, int tiles_n) {
   constexpr int BM = 128, BN = 32 * NI, BK = 64;
@@ -66,14 +69,25 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
     pb1 = pb0 + 32ll * K;
     if (NB > 2) { pb2 = pb0 + 64ll * K; pb3 = pb0 + 96ll * K; }
   }
+  // ragged form: which of this thread's W rows exist (rows past N are zero-filled)
+  const bool wok0 = !RG || n0 + srow < N, wok1 = !RG || n0 + srow + 32 < N;
+  const bool wok2 = !RG || n0 + srow + 64 < N, wok3 = !RG || n0 + srow + 96 < N;
   uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2 = uint4{0, 0, 0, 0}, rb3 = uint4{0, 0, 0, 0};
   const int soff = srow * 128 + ((skc ^ (srow & 7)) << 4);  // (srow + 32 i) & 7 == srow & 7
 #define LD16(p, k0) (*reinterpret_cast<const uint4*>((p) + (k0)))
+#define LD16P(p, k0, ok) ((ok) ? LD16(p, k0) : uint4{0, 0, 0, 0})
 #define NT_G_LOAD(k0)                                                                 \
   {                                                                                   \
-    ra0 = LD16(pa0, k0); ra1 = LD16(pa1, k0); ra2 = LD16(pa2, k0); ra3 = LD16(pa3, k0); \
-    rb0 = LD16(pb0, k0); rb1 = LD16(pb1, k0);                                         \
-    if (NB > 2) { rb2 = LD16(pb2, k0); rb3 = LD16(pb3, k0); }                         \
+    if (RG) {                                                                         \
+      const bool kok = (k0) + skc * 8 < K;                                            \
+      ra0 = LD16P(pa0, k0, kok); ra1 = LD16P(pa1, k0, kok); ra2 = LD16P(pa2, k0, kok); ra3 = LD16P(pa3, k0, kok); \
+      rb0 = LD16P(pb0, k0, kok && wok0); rb1 = LD16P(pb1, k0, kok && wok1);           \
+      if (NB > 2) { rb2 = LD16P(pb2, k0, kok && wok2); rb3 = LD16P(pb3, k0, kok && wok3); } \
+    } else {                                                                          \
+      ra0 = LD16(pa0, k0); ra1 = LD16(pa1, k0); ra2 = LD16(pa2, k0); ra3 = LD16(pa3, k0); \
+      rb0 = LD16(pb0, k0); rb1 = LD16(pb1, k0);                                       \
+      if (NB > 2) { rb2 = LD16(pb2, k0); rb3 = LD16(pb3, k0); }                       \
+    }                                                                                 \
   }
 #define ST16(base, i, v) (*reinterpret_cast<uint4*>((base) + soff + (i) * 32 * 128) = (v))
 #define NT_S_STORE(buf)                                                               \
@@ -91,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
 #pragma unroll
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = K / BK;
+  const int nk = RG ? (K + BK - 1) / BK : K / BK;
   const int fr = lane & 15, fq = lane >> 4;
   NT_G_LOAD(0)
   for (int kt = 0; kt < nk; ++kt) {
@@ -138,6 +152,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
 #pragma unroll
     for (int j = 0; j < NI / 2; ++j) {
       const int n = n0 + wn * (NI * 16) + 32 * j + 4 * gb;
+      if (RG && n >= N) continue;  // N % 8 == 0: a lane's 8 columns are all inside or all outside
       const int64_t o = m * N + n;
       f32x4 v0 = acc[mi][2 * j], v1 = acc[mi][2 * j + 1];
       if (ep.bias) { v0 += load4(ep.bias + n); v1 += load4(ep.bias + n + 4); }
@@ -185,14 +200,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
   }
 }
 
-template <int MODE, class TO, int NI>
+template <int MODE, class TO, int NI, bool RG = false>
 static int launch_nt(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
   constexpr int BN = 32 * NI;
-  const int tiles_n = N / BN;
+  const int tiles_n = RG ? (int)cdiv(N, BN) : N / BN;
   const int64_t tiles = cdiv(M, 128) * tiles_n;
   MAE_REQUIRE(tiles < (1ll << 31), "gemm: grid too large");
   const size_t lds = 2 * (128 * 64 * 2) + 2 * (BN * 64 * 2);
-  auto kern = gemm_nt_kernel<MODE, TO, NI>;
+  auto kern = gemm_nt_kernel<MODE, TO, NI, RG>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   EpiArgs ea{e.bias, e.aux, e.out, e.out2};
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, A, W, M, N, K, ea, tiles_n);
@@ -202,12 +217,13 @@ static int launch_nt(const bf16* A, const bf16* W, int64_t M, int N, int K, cons
 
 template <int MODE, class TO>
 static int launch_nt_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
+  if (K % 64 != 0 || N % 64 != 0) return launch_nt<MODE, TO, 2, true>(A, W, M, N, K, e, s);  // ragged: 128 x 64 tiles
   if (N % 128 == 0) return launch_nt<MODE, TO, 4>(A, W, M, N, K, e, s);
   return launch_nt<MODE, TO, 2>(A, W, M, N, K, e, s);
 }
 
 int mfma_linear_fwd(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
-  if (K % 64 != 0 || N % 64 != 0 || M < 1) return MFMA_UNSUPPORTED;
+  if (K % 8 != 0 || N % 8 != 0 || K < 32 || N < 16 || M < 1) return MFMA_UNSUPPORTED;
   if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)e.out | (uintptr_t)e.out2 | (uintptr_t)e.aux | (uintptr_t)e.bias) & 15) != 0)
     return MFMA_UNSUPPORTED;
   const bool f32out = e.out_dt == MAE_F32;
@@ -233,7 +249,8 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
 }
 
 // NI / KI: 16-wide tiles per wave along n / k (block tile = 32*NI x 32*KI), reduction step 64 rows of m
-template <int NI, int KI>
+// RG ("ragged"): N and K multiples of 8 only; tile columns past N / K are zero-filled on load, stores are guarded.
+template <int NI, int KI, bool RG>
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict__ dY, const bf16* __restrict__ X, int64_t M, int N,
                                                          int K, float* __restrict__ out, float* __restrict__ db,
                                                          int64_t split_stride, int tiles_n, int tiles_k, int64_t m_chunk) {
@@ -262,12 +279,12 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
     _Pragma("unroll") for (int i = 0; i < YC; ++i) {                                          \
       const int c = tid + 256 * i, row = c / (TNB / 8), cc = c % (TNB / 8);                   \
       const int64_t m = (mb) + row;                                                           \
-      ry[i] = m < mend ? *reinterpret_cast<const uint4*>(dY + m * N + n0 + cc * 8) : uint4{0, 0, 0, 0}; \
+      ry[i] = (m < mend && (!RG || n0 + cc * 8 < N)) ? *reinterpret_cast<const uint4*>(dY + m * N + n0 + cc * 8) : uint4{0, 0, 0, 0}; \
     }                                                                                         \
     _Pragma("unroll") for (int i = 0; i < XC; ++i) {                                          \
       const int c = tid + 256 * i, row = c / (TKB / 8), cc = c % (TKB / 8);                   \
       const int64_t m = (mb) + row;                                                           \
-      rx[i] = m < mend ? *reinterpret_cast<const uint4*>(X + m * K + k0 + cc * 8) : uint4{0, 0, 0, 0}; \
+      rx[i] = (m < mend && (!RG || k0 + cc * 8 < K)) ? *reinterpret_cast<const uint4*>(X + m * K + k0 + cc * 8) : uint4{0, 0, 0, 0}; \
     }                                                                                         \
   }
 #define TN_S_STORE(buf)                                                                       \
@@ -348,7 +365,10 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
   float* o = out + (int64_t)split * split_stride;
   if (do_bias && lane < 16) {  // every row of the ones-product is the same column sum: take row 0
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) db[(int64_t)split * split_stride + n0 + wn * NI * 16 + ni * 16 + lane] = accb[ni][0];
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * NI * 16 + ni * 16 + lane;
+      if (!RG || n < N) db[(int64_t)split * split_stride + n] = accb[ni][0];
+    }
   }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
@@ -356,7 +376,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const bf16* __restrict_
 #pragma unroll
     for (int ki = 0; ki < KI; ++ki) {
       const int k = k0 + wk * KI * 16 + ki * 16 + (lane >> 4) * 4;
-      store4(o + (int64_t)n * K + k, acc[ki][ni]);
+      if (!RG || (n < N && k < K)) store4(o + (int64_t)n * K + k, acc[ki][ni]);
     }
   }
 }
@@ -604,26 +624,26 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
 }
 
 static int wgrad_splits(int64_t M, int N, int K) {
-  const int tn = N % 128 == 0 ? 128 : 64, tk = K % 128 == 0 ? 128 : 64;
-  const int64_t tiles = (int64_t)(N / tn) * (K / tk);
+  const int tn = N % 128 == 0 || N % 64 != 0 ? 128 : 64, tk = K % 128 == 0 || K % 64 != 0 ? 128 : 64;  // ragged dims take 128-wide tiles
+  const int64_t tiles = (int64_t)cdiv(N, tn) * cdiv(K, tk);
   int64_t S = std::max<int64_t>(1, 512 / tiles);
   S = std::min<int64_t>(S, std::max<int64_t>(1, M / 512));  // at least 8 reduction steps per block
   return (int)std::min<int64_t>(S, 64);
 }
 
 int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K) {
-  if (N % 64 != 0 || K % 64 != 0) return 0;
+  if (N % 8 != 0 || K % 8 != 0) return 0;
   int S = wgrad_splits(M, N, K);
   if (N % T2 == 0 && K % T2 == 0) S = std::max(S, wgrad2_splits(M, N, K));
   return S > 1 ? round_up((int64_t)S * ((int64_t)N * K + N) * 4, 256) : 0;
 }
 
-template <int NI, int KI>
+template <int NI, int KI, bool RG = false>
 static int launch_tn(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* out, float* db, int64_t split_stride, int S,
                      int64_t m_chunk, hipStream_t s) {
-  const int tiles_n = N / (32 * NI), tiles_k = K / (32 * KI);
+  const int tiles_n = (int)cdiv(N, 32 * NI), tiles_k = (int)cdiv(K, 32 * KI);
   const size_t lds = 4 * 64 * TN_RS;
-  auto kern = gemm_tn_kernel<NI, KI>;
+  auto kern = gemm_tn_kernel<NI, KI, RG>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(256), lds, s, dY, X, M, N, K, out, db, split_stride, tiles_n, tiles_k, m_chunk);
   MAE_LAUNCH_CHECK();
@@ -631,7 +651,7 @@ static int launch_tn(const bf16* dY, const bf16* X, int64_t M, int N, int K, flo
 }
 
 int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, float* dW, float* db, void* slab, hipStream_t s) {
-  if (N % 64 != 0 || K % 64 != 0 || M < 1) return MFMA_UNSUPPORTED;
+  if (N % 8 != 0 || K % 8 != 0 || N < 16 || K < 16 || M < 1) return MFMA_UNSUPPORTED;
   if ((((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)db | (uintptr_t)slab) & 15) != 0) return MFMA_UNSUPPORTED;
   const bool v2 = wgrad2_ok(M, N, K);
   const int S = v2 ? wgrad2_splits(M, N, K) : wgrad_splits(M, N, K);
@@ -649,6 +669,8 @@ int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, fl
     hipLaunchKernelGGL(gemm_tn2_kernel, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(512), lds, s, dY, X, M, N, K, out, dbo, stride, tiles_n, tiles_k, m_chunk);
     MAE_LAUNCH_CHECK();
     r = 0;
+  } else if (N % 64 != 0 || K % 64 != 0) {
+    r = launch_tn<4, 4, true>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
   } else if (n128 && k128) r = launch_tn<4, 4>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
   else if (n128) r = launch_tn<4, 2>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);
   else if (k128) r = launch_tn<2, 4>(dY, X, M, N, K, out, dbo, stride, S, m_chunk, s);

@@ -167,7 +167,8 @@ def _gelu_grad(x):
 
 
 LIN_SHAPES = [(70, 144, 192), (72, 432, 144), (300, 576, 144), (145, 192, 768), (513, 384, 384), (1000, 1152, 384),
-              (257, 1536, 384), (130, 384, 1536), (36, 192, 384), (218, 192, 192), (64, 16, 32), (31, 20, 24)]
+              (257, 1536, 384), (130, 384, 1536), (36, 192, 384), (218, 192, 192), (64, 16, 32), (31, 20, 24),
+              (1300, 432, 144), (1300, 144, 576)]  # the last two: ragged MFMA tiles (N, K multiples of 8 only), several row tiles
 
 
 @pytest.mark.parametrize("M,N,K", LIN_SHAPES)
