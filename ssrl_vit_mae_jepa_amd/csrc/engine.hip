@@ -73,6 +73,7 @@ struct mae_engine {
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
+  PartialsTable ln_tab;  // LayerNorm dgamma / dbeta second stages queued by the current backward pass
   hipEvent_t pending[4] = {nullptr, nullptr, nullptr, nullptr};  // last side-stream reader of dres_c / d_hidden / d_qkv / one-off buffers
 };
 
@@ -126,7 +127,7 @@ struct Plan {
   // backward scratch
   int64_t branch_a, branch_b;  // bf16/fp32 outputs of the attention / MLP branches (added by the next LayerNorm kernel)
   int64_t dpred, d_decn, dres, dres_c, d_ln, d_att, d_qkv, d_hidden, d_xdec, dtok;
-  int64_t ln_partial, split_partial, wgrad_scratch, loss_scratch;
+  int64_t ln_partial, ln_partial_stride, split_partial, wgrad_scratch, loss_scratch;
   int64_t total;
 };
 
@@ -181,7 +182,8 @@ static Plan make_plan(const mae_engine* e, int B, int k) {
   pl.d_xdec = take(pl.Me * e->Dd * as);
   pl.dtok = take(pl.Me * e->D * as);
   const int maxd = std::max(e->D, e->Dd);
-  pl.ln_partial = take((int64_t)2 * LN_BWD_MAX_BLOCKS * maxd * 4);
+  pl.ln_partial_stride = (int64_t)2 * LN_BWD_MAX_BLOCKS * maxd * 4;  // one slot per LayerNorm of the backward pass: their
+  pl.ln_partial = take(pl.ln_partial_stride * std::min(2 * (e->depth + e->dd) + 2, (int)PartialsTable::MAX));  // second stages run in one launch at the end
   pl.split_partial = take((int64_t)512 * maxd * 4);
   int64_t wg = 0;
   auto wgs = [&](int64_t M, int N, int K) { wg = std::max(wg, linear_wgrad_scratch_bytes(M, N, K)); };
@@ -354,6 +356,9 @@ static int block_forward(const Ctx& c, const Plan& pl, const BlockRefs& r, const
   return 0;
 }
 
+// partial-sum slot of the next LayerNorm backward of this pass (its reduction is queued in e->ln_tab)
+static float* ln_slot(const Ctx& c, const Plan& pl) { return c.buf<float>(pl.ln_partial + (int64_t)(c.e->ln_tab.n % PartialsTable::MAX) * pl.ln_partial_stride); }
+
 // in: dres (fp32) / dres_c (act copy) = gradient w.r.t. the block output; out: same buffers = gradient w.r.t. the block input
 static int block_backward(const Ctx& c, const Plan& pl, const BlockRefs& r, const LayerBufs& b, int64_t M, int d, int heads, int Bn, int T,
                           int64_t x_in) {
@@ -361,7 +366,6 @@ static int block_backward(const Ctx& c, const Plan& pl, const BlockRefs& r, cons
   const int hd = d / heads, hid = e->mlp * d;
   float* dres = c.buf<float>(pl.dres);
   void* dres_c = c.buf<>(pl.dres_c);
-  float* lnp = c.buf<float>(pl.ln_partial);
   // MLP branch
   MAE_TRY(wgrad(c, pl, dres_c, c.buf<>(b.fc1_act), M, d, hid, r.fc2_w, r.fc2_b, DEP_DRESC));
   MAE_TRY(await_side(e, DEP_HIDDEN, s));  // the previous block's fc1 wgrad reads d_hidden
@@ -369,7 +373,7 @@ static int block_backward(const Ctx& c, const Plan& pl, const BlockRefs& r, cons
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_hidden), c.buf<>(b.ln2), M, hid, d, r.fc1_w, r.fc1_b, DEP_HIDDEN));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_hidden), r.fc1_w, M, hid, d, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
   MAE_TRY(await_side(e, DEP_DRESC, s));  // fc2 wgrad reads dres_c, which this kernel rewrites
-  RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), M, d, 1, dres, dres_c, c.Gp(r.ln2_w), c.Gp(r.ln2_b), lnp, s));
+  RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), M, d, 1, dres, dres_c, c.Gp(r.ln2_w), c.Gp(r.ln2_b), ln_slot(c, pl), s, &e->ln_tab));
   // attention branch
   MAE_TRY(wgrad(c, pl, dres_c, c.buf<>(b.att), M, d, d, r.proj_w, r.proj_b, DEP_DRESC));
   MAE_TRY(dgrad(c, dres_c, r.proj_w, M, d, d, MAE_EPI_NONE, c.buf<>(pl.d_att), nullptr));
@@ -378,7 +382,7 @@ static int block_backward(const Ctx& c, const Plan& pl, const BlockRefs& r, cons
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_qkv), c.buf<>(b.ln1), M, 3 * d, d, r.qkv_w, r.qkv_b, DEP_QKV));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_qkv), r.qkv_w, M, 3 * d, d, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
   MAE_TRY(await_side(e, DEP_DRESC, s));  // proj wgrad reads dres_c
-  RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(x_in), nullptr, c.P(r.ln1_w), c.buf<float>(b.mean1), c.buf<float>(b.rstd1), M, d, 1, dres, dres_c, c.Gp(r.ln1_w), c.Gp(r.ln1_b), lnp, s));
+  RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(x_in), nullptr, c.P(r.ln1_w), c.buf<float>(b.mean1), c.buf<float>(b.rstd1), M, d, 1, dres, dres_c, c.Gp(r.ln1_w), c.Gp(r.ln1_b), ln_slot(c, pl), s, &e->ln_tab));
   return 0;
 }
 
@@ -434,7 +438,7 @@ static int backward_impl(const Ctx& c, const Plan& pl) {
   for (auto& p : e->pending) p = nullptr;
   float* dres = c.buf<float>(pl.dres);
   void* dres_c = c.buf<>(pl.dres_c);
-  float* lnp = c.buf<float>(pl.ln_partial);
+  e->ln_tab.n = 0;
   // prediction head
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.dpred), c.buf<>(pl.dec_norm), pl.Mp, e->P, e->Dd, e->i_pred_w, e->i_pred_b, DEP_MISC));
   MAE_TRY(dgrad(c, c.buf<>(pl.dpred), e->i_pred_w, pl.Mp, e->P, e->Dd, MAE_EPI_NONE, c.buf<>(pl.d_decn), nullptr));
@@ -442,7 +446,7 @@ static int backward_impl(const Ctx& c, const Plan& pl) {
   MAE_TRY(await_side(e, DEP_DRESC, s));
   MAE_HIP(hipMemsetAsync(dres, 0, (size_t)pl.Md * e->Dd * 4, s));
   MAE_HIP(hipMemsetAsync(dres_c, 0, (size_t)pl.Md * e->Dd * c.as, s));
-  RUN(TK_LN_BWD, 0, pl.Mp * e->Dd * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_decn), c.act, c.buf<float>(pl.dec_x[e->dd]), c.buf<int32_t>(pl.pred_rows), c.P(e->i_dn_w), c.buf<float>(pl.dec_mean), c.buf<float>(pl.dec_rstd), pl.Mp, e->Dd, 0, dres, dres_c, c.Gp(e->i_dn_w), c.Gp(e->i_dn_b), lnp, s));
+  RUN(TK_LN_BWD, 0, pl.Mp * e->Dd * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_decn), c.act, c.buf<float>(pl.dec_x[e->dd]), c.buf<int32_t>(pl.pred_rows), c.P(e->i_dn_w), c.buf<float>(pl.dec_mean), c.buf<float>(pl.dec_rstd), pl.Mp, e->Dd, 0, dres, dres_c, c.Gp(e->i_dn_w), c.Gp(e->i_dn_b), ln_slot(c, pl), s, &e->ln_tab));
   for (int i = e->dd - 1; i >= 0; --i)
     MAE_TRY(block_backward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.B, e->L, pl.dec_x[i]));
   RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_decoder_assemble_bwd(dres, c.buf<int32_t>(pl.inv), c.buf<int32_t>(pl.keep32), pl.B, pl.k, e->L, e->Dd, c.act, c.buf<>(pl.d_xdec), c.Gp(e->i_dec_mask), c.buf<float>(pl.split_partial), s));
@@ -451,12 +455,13 @@ static int backward_impl(const Ctx& c, const Plan& pl) {
   MAE_TRY(dgrad(c, c.buf<>(pl.d_xdec), e->i_de_w, pl.Me, e->Dd, e->D, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
   // encoder final norm
   MAE_TRY(await_side(e, DEP_DRESC, s));
-  RUN(TK_LN_BWD, 0, pl.Me * e->D * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(pl.enc_x[e->depth]), nullptr, c.P(e->i_norm_w), c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), pl.Me, e->D, 0, dres, dres_c, c.Gp(e->i_norm_w), c.Gp(e->i_norm_b), lnp, s));
+  RUN(TK_LN_BWD, 0, pl.Me * e->D * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(pl.enc_x[e->depth]), nullptr, c.P(e->i_norm_w), c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), pl.Me, e->D, 0, dres, dres_c, c.Gp(e->i_norm_w), c.Gp(e->i_norm_b), ln_slot(c, pl), s, &e->ln_tab));
   for (int i = e->depth - 1; i >= 0; --i)
     MAE_TRY(block_backward(c, pl, e->enc[i], pl.enc[i], pl.Me, e->D, e->H, pl.B, pl.k, pl.enc_x[i]));
   // token assembly and patch projection
   RUN(TK_DATA, 0, pl.Me * e->D * (4 + c.as), launch_visible_grad_split(dres, c.buf<int32_t>(pl.keep32), pl.Me, e->D, c.act, c.buf<>(pl.dtok), c.Gp(e->i_cls), c.buf<float>(pl.split_partial), s));
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.dtok), c.buf<>(pl.patchA), pl.Me, e->D, e->P, e->i_patch_w, e->i_patch_b, DEP_MISC));
+  RUN(TK_LN_BWD, 0, 0, launch_sum_partials_many(e->ln_tab, s));  // dgamma / dbeta of every LayerNorm: one launch
   return join_side(c);
 }
 

@@ -170,9 +170,13 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
 
 int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_t* row_map, const float* gamma,
                          const float* mean, const float* rstd, int64_t rows, int dim, int accumulate, float* dx_io,
-                         void* dx_copy, float* dgamma, float* dbeta, float* partial, hipStream_t s) {
+                         void* dx_copy, float* dgamma, float* dbeta, float* partial, hipStream_t s, PartialsTable* defer) {
   MAE_REQUIRE(dy && x && gamma && mean && rstd && dx_io && dgamma && dbeta && partial && rows > 0, "layernorm_bwd: null buffer");
   MAE_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= 1024, "layernorm: dim %d must be a multiple of 4 in [4, 1024]", dim);
+  if (defer && defer->n == PartialsTable::MAX) {  // deep models: run what is queued before `partial` (slot 0 again) is rewritten
+    MAE_TRY(launch_sum_partials_many(*defer, s));
+    defer->n = 0;
+  }
   const int nv = (int)cdiv(dim / 4, 64);
   const int grid = (int)std::min<int64_t>(cdiv(rows, 4), LN_BWD_MAX_BLOCKS);
   const size_t lds = (size_t)8 * dim * sizeof(float);
@@ -182,6 +186,14 @@ int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_
 #undef LNB_NV
 #undef LNB
   MAE_LAUNCH_CHECK();
+  if (defer) {
+    const int i = defer->n++;
+    if (i == 0) defer->block_begin[0] = 0;
+    defer->partial[i] = partial; defer->out0[i] = dgamma; defer->out1[i] = dbeta;
+    defer->G[i] = grid; defer->C[i] = 2 * dim; defer->split[i] = dim;
+    defer->block_begin[i + 1] = defer->block_begin[i] + (int)cdiv(2 * dim, 32);
+    return 0;
+  }
   return launch_sum_partials(partial, grid, 2 * dim, dgamma, dbeta, dim, s);
 }
 

@@ -110,6 +110,40 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restri
   }
 }
 
+// the same for a table of reductions: block -> (entry, 32-column group)
+__global__ void __launch_bounds__(256) sum_partials_many_kernel(const PartialsTable tab) {
+  __shared__ __attribute__((aligned(16))) float red[32][36];
+  int e = 0;
+  while (e + 1 < tab.n && (int)blockIdx.x >= tab.block_begin[e + 1]) ++e;
+  const int blk = blockIdx.x - tab.block_begin[e];
+  const float* __restrict__ partial = tab.partial[e];
+  const int G = tab.G[e], C = tab.C[e], split = tab.split[e];
+  const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  const int c = blk * 32 + cl * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < C)
+    for (int i = rl; i < G; i += 32) acc += load4(partial + (int64_t)i * C + c);
+  store4(&red[rl][cl * 4], acc);
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int cc = blk * 32 + threadIdx.x;
+    if (cc < C) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) v += red[j][threadIdx.x];
+      if (cc < split) tab.out0[e][cc] = v; else tab.out1[e][cc - split] = v;
+    }
+  }
+}
+
+int launch_sum_partials_many(const PartialsTable& tab, hipStream_t s) {
+  if (tab.n == 0) return 0;
+  MAE_REQUIRE(tab.n <= PartialsTable::MAX, "sum_partials_many: %d entries", tab.n);
+  hipLaunchKernelGGL(sum_partials_many_kernel, dim3((unsigned)tab.block_begin[tab.n]), dim3(256), 0, s, tab);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_sum_partials(const float* partial, int G, int C, float* out0, float* out1, int split, hipStream_t s) {
   MAE_REQUIRE(partial && out0 && G > 0 && C > 0 && C % 4 == 0 && (split >= C || out1), "sum_partials: bad arguments (C %% 4 == 0)");
   hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, s, partial, G, C, out0, out1, split);

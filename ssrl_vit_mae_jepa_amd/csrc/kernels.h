@@ -69,9 +69,22 @@ int launch_transpose_many(const float* params, bf16* tbase, const TransposeTable
 int launch_layernorm_fwd(const float* x, const void* branch, float* x_out, const int32_t* row_map, const float* gamma,
                          const float* beta, float eps, int64_t rows, int dim, int y_dt, void* y, float* mean, float* rstd,
                          hipStream_t s);
+// Second stages of several two-stage column reductions, run by ONE launch (passed by value as a kernel argument): the
+// backward pass queues the dgamma / dbeta reduction of each of its LayerNorms here instead of launching 27 small,
+// latency-bound kernels between the big ones.
+struct PartialsTable {
+  static constexpr int MAX = 64;
+  int n = 0;
+  const float* partial[MAX];
+  float *out0[MAX], *out1[MAX];
+  int G[MAX], C[MAX], split[MAX], block_begin[MAX + 1];
+};
+int launch_sum_partials_many(const PartialsTable& tab, hipStream_t s);
+// `defer` != null: the dgamma / dbeta second stage is appended to *defer (the caller keeps `partial` alive and launches
+// launch_sum_partials_many later) instead of being launched here
 int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_t* row_map, const float* gamma,
                          const float* mean, const float* rstd, int64_t rows, int dim, int accumulate, float* dx_io,
-                         void* dx_copy, float* dgamma, float* dbeta, float* partial, hipStream_t s);
+                         void* dx_copy, float* dgamma, float* dbeta, float* partial, hipStream_t s, PartialsTable* defer = nullptr);
 constexpr int LN_BWD_MAX_BLOCKS = 1024;
 
 // ---- GEMM family ------------------------------------------------------------------------------------
