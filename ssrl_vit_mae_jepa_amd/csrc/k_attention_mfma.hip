@@ -48,15 +48,26 @@ __device__ __forceinline__ void stage_image(char* s, const bf16* g, int64_t gs, 
 // per image).  Rows past T and the pad chunks read clamped (valid, finite) data: every use of them is multiplied by
 // an exactly-zero probability, so they only have to be finite.  img_bytes is a multiple of 1 KiB.
 template <int HD>
-__device__ __forceinline__ void stage_image_dma(char* s, int img_bytes, const bf16* g, int64_t gs, int T, int wave, int nwaves, int lane) {
+__device__ __forceinline__ void stage_image_dma(char* s, int img_bytes, const bf16* g, int64_t gs, int T, int wave, int nwaves, int lane, int cprv) {
   constexpr int SPR = AT<HD>::RS / 16;  // 16-byte slots per padded row
   for (int blk = wave; blk * 1024 < img_bytes; blk += nwaves) {
     const int slot = blk * 64 + lane;
     int row = slot / SPR, c = slot - row * SPR;
     row = row < T ? row : T - 1;
-    c = c < AT<HD>::CPR ? c : AT<HD>::CPR - 1;
+    c = c < cprv ? c : cprv - 1;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + row * gs + c * 8),
                                      (__attribute__((address_space(3))) void*)(s + blk * 1024), 16, 0, 0);
+  }
+}
+
+// Head dims below the template's HD (the tiny config's 24 runs the HD = 32 kernels): the 16-byte slots [cprv, CPR) of every
+// row take part in the 32-deep contractions, so they are zeroed after the DMAs have landed (a DMA cannot write zeros).
+template <int HD>
+__device__ __forceinline__ void zero_pad_chunks(char* s, int rows, int cprv) {
+  const int npad = AT<HD>::CPR - cprv;
+  for (int i = threadIdx.x; i < rows * npad; i += blockDim.x) {
+    const int row = i / npad, c = cprv + (i - row * npad);
+    *reinterpret_cast<uint4*>(s + row * AT<HD>::RS + c * 16) = uint4{0, 0, 0, 0};
   }
 }
 
@@ -117,7 +128,7 @@ template <int NCH> struct BwdCap { static constexpr int v = NCH == 0 ? 1024 : 51
 
 template <int HD, int NCH>
 __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
-                                                            bf16* __restrict__ out, float* __restrict__ lse, int stagger, int gen1) {
+                                                            bf16* __restrict__ out, float* __restrict__ lse, int stagger, int gen1, int hdv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   first_generation_stagger(stagger, gen1);
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
@@ -125,14 +136,20 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
   char* sK = sQ + img;
   char* sV = sK + img;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int64_t gs = 3ll * H * HD;
-  const bf16* base = qkv + (int64_t)b * T * gs + h * HD;
+  const int64_t gs = 3ll * H * hdv;  // hdv = head dim in memory (<= HD)
+  const int cprv = hdv >> 3;
+  const bf16* base = qkv + (int64_t)b * T * gs + h * hdv;
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane);
-  stage_image_dma<HD>(sK, img, base + (int64_t)H * HD, gs, T, wave, nwaves, lane);
-  stage_image_dma<HD>(sV, img, base + 2ll * H * HD, gs, T, wave, nwaves, lane);
+  stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane, cprv);
+  stage_image_dma<HD>(sK, img, base + (int64_t)H * hdv, gs, T, wave, nwaves, lane, cprv);
+  stage_image_dma<HD>(sV, img, base + 2ll * H * hdv, gs, T, wave, nwaves, lane, cprv);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (hdv < HD) {
+    zero_pad_chunks<HD>(sQ, Tp, cprv);
+    zero_pad_chunks<HD>(sK, Tp, cprv);
+    zero_pad_chunks<HD>(sV, Tp, cprv);
+  }
   __syncthreads();
   const int g = lane >> 4, i = lane & 15;
   const float sl2 = scale * kLog2e;
@@ -189,9 +206,10 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
     const float inv = 1.0f / lsum;
     const int tq = qt * 16 + i;
     if (tq < T) {
-      bf16* po = out + ((int64_t)b * T + tq) * H * HD + h * HD + 4 * g;
+      bf16* po = out + ((int64_t)b * T + tq) * H * hdv + h * hdv + 4 * g;
 #pragma unroll
-      for (int dt = 0; dt < AT<HD>::NDT; ++dt) AT_ST(po + dt * 16, oacc[dt] * inv);
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt)
+        if (dt * 16 + 4 * g < hdv) AT_ST(po + dt * 16, oacc[dt] * inv);
       if (g == 0) lse[((int64_t)b * H + h) * T + tq] = m * scale + __logf(lsum);
     }
   }
@@ -200,7 +218,7 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
 template <int HD, int NCH>
 __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
-                                                            int Tp, int H, float scale, bf16* __restrict__ d_qkv, int stagger, int gen1) {
+                                                            int Tp, int H, float scale, bf16* __restrict__ d_qkv, int stagger, int gen1, int hdv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   first_generation_stagger(stagger, gen1);
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
@@ -211,17 +229,18 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   float* sLse = reinterpret_cast<float*>(sdO + img);  // pre-multiplied by log2(e); 1e30 on padded rows
   float* sD = sLse + Tp;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int64_t gs = 3ll * H * HD, os = (int64_t)H * HD;
-  const bf16* base = qkv + (int64_t)b * T * gs + h * HD;
-  const bf16* obase = out + (int64_t)b * T * os + h * HD;
-  const bf16* dobase = d_out + (int64_t)b * T * os + h * HD;
-  bf16* dbase = d_qkv + (int64_t)b * T * gs + h * HD;
+  const int64_t gs = 3ll * H * hdv, os = (int64_t)H * hdv;  // hdv = head dim in memory (<= HD)
+  const int cprv = hdv >> 3;
+  const bf16* base = qkv + (int64_t)b * T * gs + h * hdv;
+  const bf16* obase = out + (int64_t)b * T * os + h * hdv;
+  const bf16* dobase = d_out + (int64_t)b * T * os + h * hdv;
+  bf16* dbase = d_qkv + (int64_t)b * T * gs + h * hdv;
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane);
-  stage_image_dma<HD>(sK, img, base + os, gs, T, wave, nwaves, lane);
-  stage_image_dma<HD>(sV, img, base + 2 * os, gs, T, wave, nwaves, lane);
-  stage_image_dma<HD>(sdO, img, dobase, os, T, wave, nwaves, lane);
+  stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane, cprv);
+  stage_image_dma<HD>(sK, img, base + os, gs, T, wave, nwaves, lane, cprv);
+  stage_image_dma<HD>(sV, img, base + 2 * os, gs, T, wave, nwaves, lane, cprv);
+  stage_image_dma<HD>(sdO, img, dobase, os, T, wave, nwaves, lane, cprv);
   // D_t = dO_t . O_t with CPR lanes per row (dO chunk from the staged image, O chunk from global), shuffle-reduced.
   // The O chunks and the log-sum-exps are fetched into registers BEFORE the wait on the staging DMAs, so the two global
   // round trips of a workgroup's prologue overlap instead of following each other (up to PF slots per thread; longer
@@ -236,13 +255,19 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
     for (int it = 0; it < PF; ++it) {
       const int idx = it * blockDim.x + threadIdx.x;
       const int t = idx / CPR, cc = idx - t * CPR;
-      const bool live = idx < total && t < T;
+      const bool live = idx < total && t < T && cc < cprv;
       const int tc = live ? t : 0;
       o_pf[it] = *reinterpret_cast<const bf16x8*>(obase + tc * os + (live ? cc : 0) * 8);
       l_pf[it] = lse[((int64_t)b * H + h) * T + tc];
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (hdv < HD) {
+    zero_pad_chunks<HD>(sQ, Tp, cprv);
+    zero_pad_chunks<HD>(sK, Tp, cprv);
+    zero_pad_chunks<HD>(sV, Tp, cprv);
+    zero_pad_chunks<HD>(sdO, Tp, cprv);
+  }
   __syncthreads();
   if (pf) {
 #pragma unroll
@@ -250,7 +275,7 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
       const int idx = it * blockDim.x + threadIdx.x;
       const int t = idx / CPR, cc = idx - t * CPR;
       float D = 0.f;
-      if (idx < total && t < T) {
+      if (idx < total && t < T && cc < cprv) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(sdO + t * AT<HD>::RS + cc * 16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) D = fmaf((float)a[e], (float)o_pf[it][e], D);
@@ -267,7 +292,7 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
       const int idx = base + threadIdx.x;
       const int t = idx / CPR, cc = idx - t * CPR;
       float D = 0.f;
-      if (idx < total && t < T) {
+      if (idx < total && t < T && cc < cprv) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(sdO + t * AT<HD>::RS + cc * 16);
         const bf16x8 o = *reinterpret_cast<const bf16x8*>(obase + t * os + cc * 8);
 #pragma unroll
@@ -334,7 +359,8 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
     const int tq = qt * 16 + i;
     if (tq < T) {
 #pragma unroll
-      for (int dt = 0; dt < AT<HD>::NDT; ++dt) AT_ST(dbase + tq * gs + dt * 16 + 4 * g, dq[dt] * scale);
+      for (int dt = 0; dt < AT<HD>::NDT; ++dt)
+        if (dt * 16 + 4 * g < hdv) AT_ST(dbase + tq * gs + dt * 16 + 4 * g, dq[dt] * scale);
     }
   }
 
@@ -384,8 +410,10 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
     if (tj < T) {
 #pragma unroll
       for (int dt = 0; dt < AT<HD>::NDT; ++dt) {
-        AT_ST(dbase + tj * gs + os + dt * 16 + 4 * g, dk[dt] * scale);
-        AT_ST(dbase + tj * gs + 2 * os + dt * 16 + 4 * g, dv[dt]);
+        if (dt * 16 + 4 * g < hdv) {
+          AT_ST(dbase + tj * gs + os + dt * 16 + 4 * g, dk[dt] * scale);
+          AT_ST(dbase + tj * gs + 2 * os + dt * 16 + 4 * g, dv[dt]);
+        }
       }
     }
   }
@@ -408,28 +436,28 @@ static int attn_resident(size_t lds, int threads) {
 }
 
 static bool attn_supported(int T, int H, int hd) {
-  return (hd == 32 || hd == 64) && T >= 1 && T <= 1024 && ((int64_t)H * hd) % 8 == 0;
+  return (hd == 24 || hd == 32 || hd == 64) && T >= 1 && T <= 1024 && ((int64_t)H * hd) % 8 == 0;  // 24 runs zero-padded in the 32 kernels
 }
 
 template <int HD, int NCH>
-static int launch_attn_fwd(const bf16* qkv, int B, int T, int Tp, int H, size_t lds, float scale, bf16* out, float* lse, hipStream_t s) {
+static int launch_attn_fwd(const bf16* qkv, int B, int T, int Tp, int H, int hdv, size_t lds, float scale, bf16* out, float* lse, hipStream_t s) {
   auto kern = attn_fwd_mfma_kernel<HD, NCH>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, FwdCap<HD>::v)), lds, s, qkv, T, Tp, H, scale, out, lse, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, FwdCap<HD>::v)));
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, FwdCap<HD>::v)), lds, s, qkv, T, Tp, H, scale, out, lse, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, FwdCap<HD>::v)), hdv);
   MAE_LAUNCH_CHECK();
   return 0;
 }
 template <int HD, int NCH>
-static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int Tp, int H, size_t lds,
+static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int Tp, int H, int hdv, size_t lds,
                            float scale, bf16* d_qkv, hipStream_t s) {
   auto kern = attn_bwd_mfma_kernel<HD, NCH>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, BwdCap<NCH>::v)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, BwdCap<NCH>::v)));
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, BwdCap<NCH>::v)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, BwdCap<NCH>::v)), hdv);
   MAE_LAUNCH_CHECK();
   return 0;
 }
 #define ATTN_DISPATCH(FN, BIG, ...)                                         \
-  switch (hd * 100 + (Tp >> 5)) {                                           \
+  switch (hdt * 100 + (Tp >> 5)) {                                          \
     case 6401: return FN<64, 1>(__VA_ARGS__);                               \
     case 6402: return FN<64, 2>(__VA_ARGS__);                               \
     case 6403: return FN<64, 3>(__VA_ARGS__);                               \
@@ -438,26 +466,26 @@ static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, 
     case 3202: return FN<32, 2>(__VA_ARGS__);                               \
     case 3203: return FN<32, 3>(__VA_ARGS__);                               \
     case 3205: return FN<32, BIG>(__VA_ARGS__);                             \
-    default: return hd == 64 ? FN<64, 0>(__VA_ARGS__) : FN<32, 0>(__VA_ARGS__); \
+    default: return hdt == 64 ? FN<64, 0>(__VA_ARGS__) : FN<32, 0>(__VA_ARGS__); \
   }
 
 int mfma_attention_fwd(const bf16* qkv, int B, int T, int H, int hd, bf16* out, float* lse, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return MFMA_UNSUPPORTED;
-  const int Tp = (int)round_up(T, 32);
-  const size_t lds = (size_t)3 * round_up((int64_t)Tp * (hd * 2 + 32), 1024);
+  const int Tp = (int)round_up(T, 32), hdt = hd == 24 ? 32 : hd;
+  const size_t lds = (size_t)3 * round_up((int64_t)Tp * (hdt * 2 + 32), 1024);
   if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
   const float scale = 1.0f / sqrtf((float)hd);
-  ATTN_DISPATCH(launch_attn_fwd, 5, qkv, B, T, Tp, H, lds, scale, out, lse, s)
+  ATTN_DISPATCH(launch_attn_fwd, 5, qkv, B, T, Tp, H, hd, lds, scale, out, lse, s)
 }
 
 int mfma_attention_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int H, int hd,
                        bf16* d_qkv, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)d_qkv) & 15)) return MFMA_UNSUPPORTED;
-  const int Tp = (int)round_up(T, 32);
-  const size_t lds = (size_t)4 * round_up((int64_t)Tp * (hd * 2 + 32), 1024) + (size_t)2 * Tp * 4;
+  const int Tp = (int)round_up(T, 32), hdt = hd == 24 ? 32 : hd;
+  const size_t lds = (size_t)4 * round_up((int64_t)Tp * (hdt * 2 + 32), 1024) + (size_t)2 * Tp * 4;
   if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
   const float scale = 1.0f / sqrtf((float)hd);
-  ATTN_DISPATCH(launch_attn_bwd, 0, qkv, out, d_out, lse, B, T, Tp, H, lds, scale, d_qkv, s)
+  ATTN_DISPATCH(launch_attn_bwd, 0, qkv, out, d_out, lse, B, T, Tp, H, hd, lds, scale, d_qkv, s)
 }
 
 }  // namespace mae
