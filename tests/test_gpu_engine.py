@@ -323,6 +323,30 @@ def test_vits8_dec512_matches_oracle(dev, prec, B, tol_loss, tol_grad):
     assert (num / den) ** 0.5 < tol_grad
 
 
+# Other geometries than the reference's 96 px / patch 8 / 3 channels: the kernels are not specialised to them
+GEOMS = [
+    (O.MAEConfig(image_size=64, patch_size=16, in_chans=3, embed_dim=192, depth=2, num_heads=3, decoder_embed_dim=128, decoder_depth=1, decoder_num_heads=4), 4, 0.6),
+    (O.MAEConfig(image_size=48, patch_size=4, in_chans=1, embed_dim=64, depth=1, num_heads=2, decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2), 3, 0.8),
+    (O.MAEConfig(image_size=112, patch_size=16, in_chans=3, embed_dim=384, depth=1, num_heads=6, decoder_embed_dim=192, decoder_depth=1, decoder_num_heads=6), 9, 0.75),
+]
+
+
+@pytest.mark.parametrize("cfg,B,r", GEOMS)
+@pytest.mark.parametrize("prec,tol_loss,tol_grad", [("fp32", 1e-4, 3e-4), ("bf16", 5e-3, 5e-2)])
+def test_other_geometries_match_oracle(dev, cfg, B, r, prec, tol_loss, tol_grad):
+    model, params = build(cfg, prec, dev, r)
+    images = O.synthetic_images(B, cfg)
+    noise = O.make_noise(B, cfg.sequence_length, torch.Generator().manual_seed(11))
+    loss_ref, grads_ref, aux = O.loss_and_grads(params, cfg, images, noise, r, bf16=(prec == "bf16"))
+    loss, keep, mask = model.loss_and_grads(images.to(dev), noise.to(dev), return_indices=True)
+    assert torch.equal(keep.cpu(), aux["idx_keep"]) and torch.equal(mask.cpu(), aux["idx_mask"])
+    assert abs(loss.item() - loss_ref.item()) <= tol_loss * abs(loss_ref.item())
+    g = model.named_flat_views(model.flat_grads)
+    num = sum(float((g[n].double().cpu() - gr.double()).pow(2).sum()) for n, gr in grads_ref.items())
+    den = sum(float(gr.double().pow(2).sum()) for gr in grads_ref.values())
+    assert (num / den) ** 0.5 < tol_grad
+
+
 def test_step_is_hip_graph_capturable(dev):
     """The engine only enqueues on the caller's stream (no allocation, no sync): after one eager call (lazy attribute
     setup) a whole step can be captured into a graph and replayed with the same bits."""
