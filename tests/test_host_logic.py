@@ -95,3 +95,25 @@ def test_pretrain_cli_flags():
     from scripts.training.pretrain_mae import parse_args
     a = parse_args([])
     assert a.config == "configs/mae.yaml" and a.resume_from is None and a.output_dir_suffix == "mae_pretrain"
+
+
+def test_random_resized_crop_matches_torchvision_semantics():
+    """RandomResizedCrop(96, scale=(0.8, 1.0)) + flip of src/data.py:18-21, batched: crop boxes inside the image with
+    area in [0.8, 1] of it and aspect in [3/4, 4/3] (up to integer rounding); an identity box reproduces the input."""
+    import torch
+    from ssrl_vit_mae_jepa_amd.data import augment_batch, random_resized_crop_params
+    g = torch.Generator().manual_seed(0)
+    top, left, h, w = random_resized_crop_params(4096, 96, g)
+    assert ((top >= 0) & (left >= 0) & (top + h <= 96) & (left + w <= 96)).all()
+    frac = (h * w).double() / (96 * 96)
+    assert frac.min() > 0.78 and frac.max() <= 1.0 and 0.85 < frac.mean() < 0.90   # U[0.8, 1] thinned at the top: large non-square boxes are rejected
+    ar = w.double() / h.double()
+    assert ar.min() > 0.73 and ar.max() < 1.37
+    x = torch.rand(8, 3, 96, 96, generator=g) * 2 - 1
+    y = augment_batch(x, torch.Generator().manual_seed(1))
+    assert y.shape == x.shape and y.min() >= -1 - 1e-6 and y.max() <= 1 + 1e-6 and not torch.equal(x, y)
+    # the sampler mapping itself: a full-image box without flip is the identity (bilinear at pixel centres)
+    import torch.nn.functional as F
+    theta = torch.tensor([[[1.0, 0, 0], [0, 1.0, 0]]]).repeat(8, 1, 1)
+    ident = F.grid_sample(x, F.affine_grid(theta, list(x.shape), align_corners=False), mode="bilinear", padding_mode="border", align_corners=False)
+    assert torch.allclose(ident, x, atol=1e-5)
