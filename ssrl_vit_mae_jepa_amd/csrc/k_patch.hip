@@ -205,16 +205,17 @@ __global__ void __launch_bounds__(256) decoder_assemble_kernel(const T* __restri
                                                                const float* __restrict__ mask_token,
                                                                const float* __restrict__ pos, int64_t rows, int k, int L,
                                                                int D4, float* __restrict__ out) {
-  const int64_t total = rows * D4;
-  for (int64_t u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
-    const int64_t r = u / D4;  // r = b*L + t
-    const int d = (int)(u - r * D4) * 4;
-    const int64_t b = r / L;
-    const int t = (int)(r - b * L);
+  // D4 threads per row, 256 / D4 rows per block pass: 32-bit index math only (a 64-bit divide per element made this
+  // kernel run at half the HBM rate), the fp32 output is streamed
+  const int rpb = 256 / D4, ro = threadIdx.x / D4, d = (threadIdx.x - ro * D4) * 4;
+  if (ro >= rpb) return;
+  for (int64_t r = (int64_t)blockIdx.x * rpb + ro; r < rows; r += (int64_t)gridDim.x * rpb) {
+    const int b = (int)((uint32_t)r / (uint32_t)L);  // rows < 2^31 is checked by the launcher
+    const int t = (int)(r - (int64_t)b * L);
     const int j = inv[r];
-    f32x4 v = (j >= 0) ? load4(xdec + (b * k + j) * (int64_t)D4 * 4 + d) : load4(mask_token + d);
-    v += load4(pos + (int64_t)t * D4 * 4 + d);
-    store4(out + r * (int64_t)D4 * 4 + d, v);
+    f32x4 v = (j >= 0) ? load4(xdec + ((int64_t)b * k + j) * (D4 * 4) + d) : load4(mask_token + d);
+    v += load4(pos + t * (D4 * 4) + d);
+    store4_nt(out + r * (D4 * 4) + d, v);
   }
 }
 
@@ -222,7 +223,8 @@ int launch_decoder_assemble(const void* xdec, int dt, const int32_t* inv, const 
                             int B, int k, int L, int Dd, float* out, hipStream_t s) {
   MAE_REQUIRE(xdec && inv && mask_token && pos && out && Dd % 4 == 0, "decoder_assemble: bad arguments");
   const int64_t rows = (int64_t)B * L;
-  const int grid = (int)std::min<int64_t>(cdiv(rows * (Dd / 4), 256), 256 * 16);
+  MAE_REQUIRE(Dd / 4 <= 256 && rows < (1ll << 31), "decoder_assemble: Dd <= 1024 and B * L < 2^31");
+  const int grid = (int)std::min<int64_t>(cdiv(rows, 256 / (Dd / 4)), 256 * 16);
   if (dt == MAE_BF16)
     hipLaunchKernelGGL((decoder_assemble_kernel<bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)xdec, inv, mask_token, pos, rows, k, L, Dd / 4, out);
   else
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256) decoder_assemble_bwd_kernel(const float* 
       if (j < 0) {
         acc += v;
       } else {
-        const int64_t b = r / L;
+        const int64_t b = (uint32_t)r / (uint32_t)L;  // rows < 2^31 (checked by the launcher)
         store4(d_xdec + (b * k + j) * (int64_t)D + d0, v);
       }
     }
@@ -266,6 +268,7 @@ int launch_decoder_assemble_bwd(const float* dx, const int32_t* inv, const int32
   MAE_REQUIRE(dx && inv && d_xdec && d_mask_token && partial && Dd % 4 == 0 && Dd <= 1024,
               "decoder_assemble_bwd: bad arguments (need Dd %% 4 == 0, Dd <= 1024)");
   const int64_t rows = (int64_t)B * L;
+  MAE_REQUIRE(rows < (1ll << 31), "decoder_assemble_bwd: B * L < 2^31");
   const int RPI = 256 / (Dd / 4);
   const int G = (int)std::min<int64_t>(cdiv(rows, RPI), SPLIT_BLOCKS);
   const size_t lds = (size_t)RPI * Dd * sizeof(float);
