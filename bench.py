@@ -86,6 +86,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=2000, help="images per GPU (weak scaling)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the second, event-instrumented pass (no roofline object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="collective backend: nccl (= RCCL, the measured path) or gloo (rehearsal of the N > 1 control flow)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0 (with --backend gloo on a one-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,10 +97,15 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            torch.distributed.init_process_group(args.backend)
 
     from ssrl_vit_mae_jepa_amd import MAEPretrainModule
     B = args.batch
@@ -156,7 +163,7 @@ def main() -> None:
             "value": img_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ViT-S/8 96px MAE (enc 384x12x6h, dec 192x2x6h, mask_ratio 0.75), batch 2000/GPU, full step",
+            "config": {"workload": f"ViT-S/8 96px MAE (enc 384x12x6h, dec 192x2x6h, mask_ratio 0.75), batch {B}/GPU, full step",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_image_step": fl / 1e9},
             "final_loss": float(loss.item()),
