@@ -162,7 +162,49 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
 #pragma unroll
     for (int dt = 0; dt < AT<HD>::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, lsum = 0.f;
+    if constexpr (NCH > 0) {
+      // unrolled lengths: exact two-pass softmax.  All the scores of the row tile stay in registers (8 per chunk), the
+      // maximum is taken once, and the per-chunk rescale of the online form (lane-group max, alpha = exp2(m - m'),
+      // oacc *= alpha, lsum update: ~12 of ~60 VALU instructions per chunk in a VALU-bound kernel) disappears.
+      constexpr int NC = NCH > 0 ? NCH : 1;
+      f32x4 s0[NC], s1[NC];
 #pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        s0[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[c] = s0[c];
+#pragma unroll
+        for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
+          s0[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32, ks, lane), qf[ks], s0[c], 0, 0, 0);
+          s1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32 + 16, ks, lane), qf[ks], s1[c], 0, 0, 0);
+        }
+      }
+      {  // only the last chunk holds keys past T
+        const int j0 = (NC - 1) * 32 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (j0 + r >= T) s0[NC - 1][r] = -INFINITY;
+          if (j0 + 16 + r >= T) s1[NC - 1][r] = -INFINITY;
+        }
+      }
+      float mc = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+        mc = fmaxf(mc, fmaxf(fmaxf(fmaxf(s0[c][0], s0[c][1]), fmaxf(s0[c][2], s0[c][3])), fmaxf(fmaxf(s1[c][0], s1[c][1]), fmaxf(s1[c][2], s1[c][3]))));
+      m = group_max(mc);  // finite: key 0 is always valid
+      const float mn2 = m * sl2;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s0[c][r] = __builtin_amdgcn_exp2f(fmaf(s0[c][r], sl2, -mn2));  // raw v_exp_f32: arguments <= 0, exp2(-inf) = 0
+          s1[c][r] = __builtin_amdgcn_exp2f(fmaf(s1[c][r], sl2, -mn2));
+          lsum += s0[c][r] + s1[c][r];
+        }
+        const bf16x8 pf = pack8(s0[c], s1[c]);
+#pragma unroll
+        for (int dt = 0; dt < AT<HD>::NDT; ++dt)
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sV, c * 32, dt * 16, lane), pf, oacc[dt], 0, 0, 0);
+      }
+    } else {
     for (int c = 0; c < nchunks; ++c) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -172,7 +214,7 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
       }
       // lane: query i, keys j = c*32 + 4g + r (s0) and c*32 + 16 + 4g + r (s1)
       const int j0 = c * 32 + 4 * g;
-      if (NCH > 0 ? c == NCH - 1 : c * 32 + 32 > T) {  // only the last chunk holds keys past T (static when unrolled, else wave-uniform)
+      if (c * 32 + 32 > T) {  // only the last chunk holds keys past T (wave-uniform)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (j0 + r >= T) s0[r] = -INFINITY;
@@ -201,6 +243,7 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
         oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sV, c * 32, dt * 16, lane), pf, oacc[dt], 0, 0, 0);
       }
       m = mn;
+    }
     }
     lsum = group_sum(lsum);
     const float inv = 1.0f / lsum;
