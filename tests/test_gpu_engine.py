@@ -347,6 +347,26 @@ def test_other_geometries_match_oracle(dev, cfg, B, r, prec, tol_loss, tol_grad)
     assert (num / den) ** 0.5 < tol_grad
 
 
+@pytest.mark.parametrize("B", [1, 7, 129, 1001])
+def test_vits8_bf16_tracks_fp32_engine_over_batch_sizes(dev, B):
+    """Ragged row counts through every kernel (M = 36 B and 145 B rows: partial GEMM tiles, partial wgrad steps, one
+    workgroup per (image, head)): the bf16 path stays within bf16 noise of the exact-fp32 path of the same engine."""
+    cfg = O.VIT_S8_YAMLDEC
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(B)
+    images = torch.rand(B, 3, 96, 96, device=dev, generator=g) * 2 - 1
+    noise = torch.rand(B, cfg.sequence_length, device=dev, generator=g)
+    for prec in ("fp32", "bf16"):
+        torch.manual_seed(3)
+        model = MaskedAutoencoder(*cfg_dicts(cfg, prec)).to(dev)
+        loss = model.loss_and_grads(images, noise)
+        torch.cuda.synchronize()
+        assert torch.isfinite(model.flat_grads).all()
+        out[prec] = (float(loss), model.flat_grads.clone())
+    assert abs(out["bf16"][0] - out["fp32"][0]) <= 1e-3 * abs(out["fp32"][0])
+    assert float((out["bf16"][1] - out["fp32"][1]).norm() / out["fp32"][1].norm()) < 5e-2
+
+
 def test_step_is_hip_graph_capturable(dev):
     """The engine only enqueues on the caller's stream (no allocation, no sync): after one eager call (lazy attribute
     setup) a whole step can be captured into a graph and replayed with the same bits."""
