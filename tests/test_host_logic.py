@@ -117,3 +117,36 @@ def test_random_resized_crop_matches_torchvision_semantics():
     theta = torch.tensor([[[1.0, 0, 0], [0, 1.0, 0]]]).repeat(8, 1, 1)
     ident = F.grid_sample(x, F.affine_grid(theta, list(x.shape), align_corners=False), mode="bilinear", padding_mode="border", align_corners=False)
     assert torch.allclose(ident, x, atol=1e-5)
+
+
+def test_checkpoints_are_consumable_by_the_reference_encoder_loader(tmp_path):
+    """The reference's fine-tune script (scripts/training/train_mae.py:101-139) takes ``ckpt.get("state_dict", ckpt)``, finds
+    the first of the prefixes 'model.encoder.' / 'encoder.' / 'module.encoder.', strips it and loads the rest into
+    ``mae.encoder`` with strict=False.  Both files the pretrain CLI writes (Lightning-shaped .ckpt and the raw vit-mae.pt)
+    must come through that procedure with every encoder tensor matched and nothing unexpected."""
+    import torch
+    from ssrl_vit_mae_jepa_amd import MAEPretrainModule, MaskedAutoencoder
+    g = dict(image_size=32, patch_size=8, in_chans=3)
+    e = dict(embed_dim=48, depth=2, num_heads=2)
+    d = dict(decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2)
+    tcfg = dict(mask_ratio_start=0.75, mask_ratio_end=0.75, mask_ramp_epochs=5, total_epochs=8, warmup_epochs=2,
+                batch_size=256, base_learning_rate=1.5e-4, weight_decay=0.05)
+    torch.manual_seed(0)
+    module = MAEPretrainModule(dict(general=g, encoder=e, decoder=d), tcfg)
+    lightning_like = {"state_dict": {f"model.{k}": v.clone() for k, v in module.model.state_dict().items()}, "epoch": 0}
+    raw = {k: v.clone() for k, v in module.model.state_dict().items()}
+    torch.save(lightning_like, tmp_path / "last.ckpt"); torch.save(raw, tmp_path / "vit-mae.pt")
+    for name, want_prefix in (("last.ckpt", "model.encoder."), ("vit-mae.pt", "encoder.")):
+        ckpt = torch.load(tmp_path / name, map_location="cpu", weights_only=True)
+        state_dict = ckpt.get("state_dict", ckpt)
+        prefix = next((p for p in ("model.encoder.", "encoder.", "module.encoder.") if any(k.startswith(p) for k in state_dict)), None)
+        assert prefix == want_prefix
+        encoder_state = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        torch.manual_seed(1)
+        fresh = MaskedAutoencoder(g, e, d)
+        missing, unexpected = fresh.encoder.load_state_dict(encoder_state, strict=False)
+        assert not missing and not unexpected and len(encoder_state) == 2 * 12 + 7  # 2 blocks x 12 tensors + mask/cls/pos/patch(2)/norm(2)
+        for k, v in encoder_state.items():
+            assert torch.equal(fresh.encoder.state_dict()[k], v)
+        # timm names below `vit.` (what ViTClassifierTrainModule receives as pretrained_encoder)
+        assert {"vit.cls_token", "vit.pos_embed", "vit.patch_embed.proj.weight", "vit.blocks.1.mlp.fc2.bias", "vit.norm.weight"} <= set(encoder_state)
