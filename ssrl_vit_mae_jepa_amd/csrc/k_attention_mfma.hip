@@ -12,6 +12,9 @@
 // Reference behaviour: F.scaled_dot_product_attention inside timm Attention.forward (no mask, no dropout).
 #include "gemm_mfma.h"
 
+#ifndef MAE_ATT_DMA_POLICY
+#define MAE_ATT_DMA_POLICY 0  // cache-policy bits of the staging DMAs (2 = nt)
+#endif
 #ifdef MAE_ATT_NT
 #define AT_ST store4_nt
 #else
@@ -56,7 +59,7 @@ __device__ __forceinline__ void stage_image_dma(char* s, int img_bytes, const bf
     row = row < T ? row : T - 1;
     c = c < cprv ? c : cprv - 1;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + row * gs + c * 8),
-                                     (__attribute__((address_space(3))) void*)(s + blk * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(s + blk * 1024), 16, 0, MAE_ATT_DMA_POLICY);
   }
 }
 

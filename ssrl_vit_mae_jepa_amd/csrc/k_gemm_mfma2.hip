@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
         m = m < M ? m : M - 1;
         const bf16* q = reinterpret_cast<const bf16*>(aux) + m * N + n0 + wn * (NI * 16) + 4 * gb;
 #pragma unroll
-        for (int j = 0; j < NI / 2; ++j) qa[PREF ? j : 0][PREF ? mi : 0] = *reinterpret_cast<const bf16x8*>(q + 32 * j);
+        for (int j = 0; j < NI / 2; ++j) qa[PREF ? j : 0][PREF ? mi : 0] = *reinterpret_cast<const bf16x8*>(q + 32 * j);  // (a non-temporal load measured 0.1 ms per step slower)
       }
     }
     const char* a_base = smem + cs * STAGE + (wm * WROWS + fr) * 128;

@@ -5,7 +5,7 @@
 #include "kernels.h"
 
 #ifndef MAE_LN_NT
-#define MAE_LN_NT 1  // bit 0: fp32 residual-stream / dx stores stream (measured -0.4 ms per step); bit 1: the bf16 operand copies too (no gain)
+#define MAE_LN_NT 5  // bit 0: fp32 residual-stream / dx stores stream (measured -0.4 ms per step); bit 1: the bf16 operand copies too (no gain); bit 2: the read-once inputs (x, branch, dy) are loaded non-temporally (-0.2 ms, mostly in the GEMMs that follow)
 #endif
 #if MAE_LN_NT & 1
 #define LN_ST_A store4_nt
@@ -16,6 +16,11 @@
 #define LN_ST_B store4_nt
 #else
 #define LN_ST_B store4
+#endif
+#if MAE_LN_NT & 4
+#define LN_LD load4_nt
+#else
+#define LN_LD load4
 #endif
 
 namespace mae {
@@ -41,9 +46,9 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < D4) {
-        v[i] = load4(px + c * 4);
+        v[i] = LN_LD(px + c * 4);
         if (ADD) {
-          v[i] += load4(branch + src * dim + c * 4);
+          v[i] += LN_LD(branch + src * dim + c * 4);
           LN_ST_A(x_out + src * dim + c * 4, v[i]);
         }
         sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -129,8 +134,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict_
     for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < D4) {
-        const f32x4 d = load4(dy + r * dim + c * 4);
-        xh[i] = (load4(x + src * dim + c * 4) - mu) * rs;
+        const f32x4 d = LN_LD(dy + r * dim + c * 4);
+        xh[i] = (LN_LD(x + src * dim + c * 4) - mu) * rs;
         g[i] = d * gam[i];
         dg[i] += d * xh[i];
         db[i] += d;
