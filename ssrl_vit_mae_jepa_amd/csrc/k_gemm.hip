@@ -122,6 +122,15 @@ static int check_epi(const Epi& e, int dt, const char* who) {
   return 0;
 }
 
+int num_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+  }();
+  return n;
+}
+
 int launch_linear_fwd(const void* A, const void* W, int64_t M, int N, int K, int dt, const Epi& e, hipStream_t s) {
   MAE_REQUIRE(A && W && M > 0 && N > 0 && K > 0, "linear_fwd: bad arguments");
   MAE_TRY(check_epi(e, dt, "linear_fwd"));

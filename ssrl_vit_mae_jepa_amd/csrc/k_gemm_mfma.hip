@@ -592,7 +592,7 @@ static bool wgrad2_ok(int64_t M, int N, int K) {
 }
 static int wgrad2_splits(int64_t M, int N, int K) {
   const int64_t tiles = (int64_t)(N / T2) * (K / T2);
-  int64_t S = std::max<int64_t>(1, 256 / tiles);                  // one block per CU (144 KiB of LDS)
+  int64_t S = std::max<int64_t>(1, num_cus() / tiles);            // one block per CU (144 KiB of LDS)
   S = std::min<int64_t>(S, std::max<int64_t>(1, M / 256));        // at least 4 reduction steps per block
   return (int)S;
 }

@@ -316,7 +316,7 @@ static int launch_nt2(const bf16* A, const bf16* W, int64_t M, int N, int K, con
   const int64_t T = cdiv(M, G_::BM) * (N / G_::BN);
   MAE_REQUIRE(T < (1ll << 30), "gemm: too many tiles");
   const int tiles_m = (int)cdiv(M, G_::BM), tiles_n = N / G_::BN;
-  const int grid = (int)std::min<int64_t>(T, 256);
+  const int grid = (int)std::min<int64_t>(T, num_cus());  // one persistent workgroup per CU
   if (e.bias) {
     auto kern = gemm_nt2_kernel<MODE, TO, true, NI, MI>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
@@ -337,7 +337,7 @@ static bool prefer_bm192(int64_t M, int N) {
   if (force == 192) return true;
   if (force == 256) return false;
   const int64_t t256 = cdiv(M, 256) * (N / 192), t192 = cdiv(M, 192) * (N / 192);
-  const int64_t c256 = cdiv(t256, 256) * 256, c192 = cdiv(t192, 256) * 192;
+  const int64_t c256 = cdiv(t256, num_cus()) * 256, c192 = cdiv(t192, num_cus()) * 192;
   return c192 * 100 < c256 * 95;  // measured: 192-row tiles win whenever they save a round (decoder fc2 130 vs 143 us, pred head 69 vs 79 us)
 }
 

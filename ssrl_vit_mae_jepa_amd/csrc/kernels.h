@@ -87,6 +87,9 @@ int launch_layernorm_bwd(const void* dy, int dy_dt, const float* x, const int32_
                          void* dx_copy, float* dgamma, float* dbeta, float* partial, hipStream_t s, PartialsTable* defer = nullptr);
 constexpr int LN_BWD_MAX_BLOCKS = 1024;
 
+// Compute units of the current device (256 on MI355X), queried once: the persistent GEMMs launch one workgroup per CU.
+int num_cus();
+
 // ---- GEMM family ------------------------------------------------------------------------------------
 struct Epi {
   int mode = MAE_EPI_NONE;
