@@ -4,6 +4,7 @@
 mask_ratio 0.75, bf16 MFMA operands / fp32 accumulate, batch 2000 per GPU (BASELINE.json configs[1]; SURVEY 8d "2a").
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --config configs/vitb16_dec512.yaml --batch 512      # another configs/*.yaml model; the default line is unchanged
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One JSON line on rank 0.  `value` is whole-job images/s with inputs resident in HBM (K steps, barrier + synchronize on
@@ -38,9 +39,12 @@ TRAIN = dict(mask_ratio_start=0.75, mask_ratio_end=0.75, mask_ramp_epochs=5, tot
              batch_size=2000, base_learning_rate=1.5e-4, weight_decay=0.05)
 
 
-def flops_per_image_step() -> float:
+def flops_per_image_step(general=GENERAL, encoder=ENCODER, decoder=DECODER) -> float:
     """2*MAC, GEMMs + attention matmuls, patch-embed on visible patches only, step = 3 x fwd."""
-    L, k, P, D, Dd, depth, dd = 145, 36, 192, 384, 192, 12, 2
+    N = (general["image_size"] // general["patch_size"]) ** 2
+    L, P = N + 1, general["patch_size"] ** 2 * general.get("in_chans", 3)
+    k = max(1, int(L * (1 - general.get("mask_ratio", 0.75))))
+    D, depth, Dd, dd = encoder["embed_dim"], encoder["depth"], decoder["decoder_embed_dim"], decoder["decoder_depth"]
     m = L - k
     fwd = (2 * (k - 1) * P * D + depth * k * 24 * D * D + depth * 4 * k * k * D + 2 * k * D * Dd
            + dd * L * 24 * Dd * Dd + dd * 4 * L * L * Dd + 2 * m * Dd * P)
@@ -57,25 +61,44 @@ def pmc_traffic(kernel: str):
         return None
 
 
-def cpu_baseline(batch: int = 64, steps: int = 3) -> dict:
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(general, encoder, decoder, label: str, batch: int = 64, steps: int = 3) -> dict:
     """The oracle (CPU restatement of the reference path) timed on this box's host cores: the checker used as a
-    reported baseline, never as the product."""
+    reported baseline, never as the product.  Two legs: fp32 matmuls at "highest" (the parity setting) and
+    the reference's literal torch.set_float32_matmul_precision("medium") (scripts/utils.py:22)."""
     from oracle import mae_oracle as O
-    torch.set_float32_matmul_precision("highest")
-    cfg = O.VIT_S8_YAMLDEC
-    params = O.init_params(cfg, 73)
-    state = {}
-    images = O.synthetic_images(batch, cfg)
+    cfg = O.MAEConfig.from_dicts(general, encoder, decoder)
     lr = O.effective_lr(1.5e-4, 2000) * O.lr_lambda(0, 20, 800)
-    times = []
-    for step in range(1, steps + 2):
-        noise = O.make_noise(batch, cfg.sequence_length, torch.Generator().manual_seed(73 + step))
-        t0 = time.perf_counter()
-        O.train_step(params, cfg, state, images, noise, lr, step)
-        times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": batch / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle.train_step fp32 'highest', ViT-S/8 + dec 192x2x6, batch {batch}, 1 warm-up + {steps} timed steps, median"}
+
+    def leg(precision: str, n: int) -> float:
+        torch.set_float32_matmul_precision(precision)
+        params = O.init_params(cfg, 73)
+        state = {}
+        images = O.synthetic_images(batch, cfg)
+        times = []
+        for step in range(1, n + 2):
+            noise = O.make_noise(batch, cfg.sequence_length, torch.Generator().manual_seed(73 + step))
+            t0 = time.perf_counter()
+            O.train_step(params, cfg, state, images, noise, lr, step, mask_ratio=general.get("mask_ratio", 0.75))
+            times.append(time.perf_counter() - t0)
+        return batch / sorted(times[1:])[len(times[1:]) // 2]
+
+    hi = leg("highest", steps)
+    med = leg("medium", max(1, steps - 1))
+    torch.set_float32_matmul_precision("highest")
+    return {"value": hi, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
+            "value_matmul_precision_medium": med,
+            "sample": f"oracle.train_step fp32, {label}, batch {batch}, 1 warm-up + {steps} timed steps ('highest') / "
+                      f"{max(1, steps - 1)} ('medium', the reference's literal setting), median"}
 
 
 def main() -> None:
@@ -83,7 +106,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=2000, help="images per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling); default 2000 (BASELINE configs[1])")
+    ap.add_argument("--config", default=None, help="a configs/*.yaml model instead of the default ViT-S/8 + dec 192x2x6 workload")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the second, event-instrumented pass (no roofline object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="collective backend: nccl (= RCCL, the measured path) or gloo (rehearsal of the N > 1 control flow)")
@@ -108,17 +132,29 @@ def main() -> None:
             torch.distributed.init_process_group(args.backend)
 
     from ssrl_vit_mae_jepa_amd import MAEPretrainModule
-    B = args.batch
-    tcfg = dict(TRAIN, batch_size=B * world)
+    general, encoder, decoder, train = GENERAL, ENCODER, DECODER, TRAIN
+    if args.config:
+        import yaml
+        y = yaml.safe_load(open(args.config))
+        general = dict(mask_ratio=float(y["pretrain"].get("mask_ratio_end", 0.75)), engine_precision="bf16", **y["model"]["general"])
+        encoder, decoder = y["model"]["encoder"], y["model"]["decoder"]
+        train = dict(y["pretrain"], mask_ratio_start=general["mask_ratio"], mask_ratio_end=general["mask_ratio"])
+    B = args.batch if args.batch else (2000 if not args.config else max(1, int(train["batch_size"]) // 8))
+    img, chans = int(general["image_size"]), int(general.get("in_chans", 3))
+    label = (f"ViT {encoder['embed_dim']}x{encoder['depth']}x{encoder['num_heads']}h /{general['patch_size']} {img}px MAE, dec "
+             f"{decoder['decoder_embed_dim']}x{decoder['decoder_depth']}x{decoder['decoder_num_heads']}h")
+    if not args.config:
+        label = "ViT-S/8 96px MAE (enc 384x12x6h, dec 192x2x6h, mask_ratio 0.75)"
+    tcfg = dict(train, batch_size=B * world)
     torch.manual_seed(73)
-    module = MAEPretrainModule(dict(general=GENERAL, encoder=ENCODER, decoder=DECODER), tcfg).to(dev)
+    module = MAEPretrainModule(dict(general=general, encoder=encoder, decoder=decoder), tcfg).to(dev)
     module.on_train_epoch_start()
     model = module.model
     L = model.sequence_length
 
     # synthetic inputs, resident in HBM before the timed region; every rank draws the global tensors and keeps its rows
     g = torch.Generator(device=dev).manual_seed(73)
-    images = (torch.rand(B * world, 3, 96, 96, device=dev, generator=g) * 2 - 1)[rank * B:(rank + 1) * B].contiguous()
+    images = (torch.rand(B * world, chans, img, img, device=dev, generator=g) * 2 - 1)[rank * B:(rank + 1) * B].contiguous()
     total = args.warmup + args.steps
     noises = [torch.rand(B * world, L, device=dev, generator=g)[rank * B:(rank + 1) * B].contiguous() for _ in range(total)]
 
@@ -130,12 +166,18 @@ def main() -> None:
     for i in range(args.warmup):
         module.fused_training_step(images, noises[i])
     sync()
+    # one event per step on the launch stream (torch's current stream IS the engine's launch stream): p10/p50/p90
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     loss = None
+    marks[0].record()
     for i in range(args.steps):
         loss = module.fused_training_step(images, noises[args.warmup + i])
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))]  # noqa: E731
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -157,16 +199,20 @@ def main() -> None:
         kernels = model.engine.timers_read()
     if rank == 0:
         img_s = B * world * args.steps / elapsed
-        fl = flops_per_image_step()
+        fl = flops_per_image_step(general, encoder, decoder)
         out = {
-            "metric": "images/sec pretrain step (fwd+bwd+opt), ViT-S/8 96px MAE, 1/2/4/8 MI355X",  # BASELINE.json's metric, verbatim
+            # BASELINE.json's metric, verbatim, for the default workload; a --config run names its own model
+            "metric": ("images/sec pretrain step (fwd+bwd+opt), ViT-S/8 96px MAE, 1/2/4/8 MI355X" if not args.config
+                       else f"images/sec pretrain step (fwd+bwd+opt), {label}"),
             "value": img_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"ViT-S/8 96px MAE (enc 384x12x6h, dec 192x2x6h, mask_ratio 0.75), batch {B}/GPU, full step",
+            "config": {"workload": f"{label}, batch {B}/GPU, full step",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "algorithmic_gflop_per_image_step": fl / 1e9},
             "final_loss": float(loss.item()),
+            "step_ms_percentiles": {"p10": pct(0.1), "p50": pct(0.5), "p90": pct(0.9), "min": step_ms[0], "max": step_ms[-1],
+                                    "measured_with": "one HIP event per step on the launch stream, inside the timed region"},
             "step_mfma_frac": img_s / world * fl / (PEAK_BF16_TFLOPS * 1e12),
         }
         if kernels:
@@ -184,7 +230,7 @@ def main() -> None:
                                   "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                               for n, v in kernels.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(general, encoder, decoder, label, batch=64 if img <= 96 else 8)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -135,6 +135,22 @@ int mae_engine_loss_and_grads(mae_engine_t* e, const float* params, const void* 
                               void* workspace, int64_t workspace_bytes, float* grads, float* loss_out,
                               int64_t* idx_keep_out, int64_t* idx_mask_out, void* stream);
 
+/* Data-parallel overlap (no counterpart in the reference, which runs devices=1, scripts/training/pretrain_mae.py:118).
+ * The backward pass finishes the gradient arena from its END: the decoder's tensors first, then encoder block depth-1,
+ * ..., block 0, patch projection and class token last.  mae_engine_grad_ready_points reports those points in the order
+ * they are reached: reaching point j means grads[offsets[j] .. trainable_elems) is final.  Returns the number of
+ * points (encoder depth + 1; the last one has offset 0); fills at most max_points offsets (offsets may be NULL). */
+int32_t mae_engine_grad_ready_points(const mae_engine_t* e, int64_t* offsets, int32_t max_points);
+/* mae_engine_loss_and_grads that also records ready_events[j] (a hipEvent_t passed as void*; NULL = skip the point) on
+ * `stream` when point j is reached, so that the caller can start the all-reduce of that arena range on another stream
+ * while the rest of the backward pass still runs.  num_ready must equal mae_engine_grad_ready_points(). Results are
+ * bit-identical to mae_engine_loss_and_grads. */
+int mae_engine_loss_and_grads_phased(mae_engine_t* e, const float* params, const void* wcache, const float* images,
+                                     const float* noise, int32_t batch, int32_t num_keep, float grad_scale,
+                                     void* workspace, int64_t workspace_bytes, float* grads, float* loss_out,
+                                     int64_t* idx_keep_out, int64_t* idx_mask_out, void* const* ready_events,
+                                     int32_t num_ready, void* stream);
+
 /* clip_grad_norm_(max_norm, L2) (scripts/training/pretrain_mae.py:124-125) followed by
  * torch.optim.AdamW single-group step (src/training/mae.py:59-65) over the trainable range,
  * then the operand-copy refresh.  step is 1-based.  stats_out[0] = total grad norm (pre-clip),

@@ -112,6 +112,10 @@ VIT_S8_YAMLDEC = MAEConfig(image_size=96, patch_size=8, in_chans=3, embed_dim=38
 # the code-default decoder width / depth (src/models/mae.py:49-50) with a valid head count
 VIT_S8_DEC512 = MAEConfig(image_size=96, patch_size=8, in_chans=3, embed_dim=384, depth=12, num_heads=6,
                           decoder_embed_dim=512, decoder_depth=4, decoder_num_heads=8)
+# BASELINE.json configs[3] / SURVEY 8d config 4: ViT-B/16 224 px with the MAE-paper decoder (512 x 8 x 16 heads);
+# L = 197, k = 49, m = 148, P = 768.  The reference's ctor accepts it (src/models/mae.py:28-52) but never ran it.
+VIT_B16_DEC512 = MAEConfig(image_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12,
+                           decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16)
 
 
 # ----------------------------------------------------------------------------

@@ -64,6 +64,8 @@ SIGNATURES = {
     "mae_mse_loss": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp]),
     "mae_engine_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mae_engine_loss_and_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mae_engine_grad_ready_points": (_i32, [_vp, _pp(_i64), _i32]),
+    "mae_engine_loss_and_grads_phased": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _pp(_vp), _i32, _vp]),
     "mae_engine_optimizer_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _vp, _vp]),
     "mae_engine_timers_enable": (C.c_int, [_vp, _i32]),
     "mae_engine_timer_count": (_i32, [_vp]),

@@ -266,6 +266,7 @@ struct Ctx {
   hipStream_t s;
   int act;
   int64_t as;
+  void* const* ready = nullptr;  // hipEvent_t per gradient-ready point (entries may be null), or null
   const float* P(int i) const { return params + e->params[i].offset; }
   float* Gp(int i) const { return grads + e->params[i].offset; }
   // GEMM operand view of weight i: (out, in) row-major in the activation dtype
@@ -431,6 +432,21 @@ static int forward_decoder_impl(const Ctx& c, const Plan& pl, float* x_pred_out)
   return 0;
 }
 
+// Gradient-ready points (data-parallel overlap): point 0 = the whole decoder range of the gradient arena is final, point
+// i (1 .. depth-1) = encoder block depth-i and everything behind it, point depth = everything.  Reaching a point that the
+// caller gave an event for first retires what was deferred (LayerNorm dgamma / dbeta second stages, side-stream wgrads).
+static int reach_point(const Ctx& c, int j) {
+  mae_engine* e = c.e; hipStream_t s = c.s;
+  if (!c.ready || !c.ready[j]) return 0;
+  if (e->ln_tab.n > 0) {
+    RUN(TK_LN_BWD, 0, 0, launch_sum_partials_many(e->ln_tab, s));
+    e->ln_tab.n = 0;  // slots are reused in stream order behind the reduction just enqueued
+  }
+  MAE_TRY(join_side(c));
+  MAE_HIP(hipEventRecord((hipEvent_t)c.ready[j], s));
+  return 0;
+}
+
 // dpred (act dtype) must already sit in the workspace
 static int backward_impl(const Ctx& c, const Plan& pl) {
   mae_engine* e = c.e; hipStream_t s = c.s;
@@ -453,16 +469,22 @@ static int backward_impl(const Ctx& c, const Plan& pl) {
   // decoder_embed
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_xdec), c.buf<>(pl.enc_norm), pl.Me, e->Dd, e->D, e->i_de_w, e->i_de_b, DEP_MISC));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_xdec), e->i_de_w, pl.Me, e->Dd, e->D, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
+  MAE_TRY(reach_point(c, 0));
   // encoder final norm
   MAE_TRY(await_side(e, DEP_DRESC, s));
   RUN(TK_LN_BWD, 0, pl.Me * e->D * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(pl.enc_x[e->depth]), nullptr, c.P(e->i_norm_w), c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), pl.Me, e->D, 0, dres, dres_c, c.Gp(e->i_norm_w), c.Gp(e->i_norm_b), ln_slot(c, pl), s, &e->ln_tab));
-  for (int i = e->depth - 1; i >= 0; --i)
+  for (int i = e->depth - 1; i >= 0; --i) {
     MAE_TRY(block_backward(c, pl, e->enc[i], pl.enc[i], pl.Me, e->D, e->H, pl.B, pl.k, pl.enc_x[i]));
+    if (i > 0) MAE_TRY(reach_point(c, e->depth - i));
+  }
   // token assembly and patch projection
   RUN(TK_DATA, 0, pl.Me * e->D * (4 + c.as), launch_visible_grad_split(dres, c.buf<int32_t>(pl.keep32), pl.Me, e->D, c.act, c.buf<>(pl.dtok), c.Gp(e->i_cls), c.buf<float>(pl.split_partial), s));
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.dtok), c.buf<>(pl.patchA), pl.Me, e->D, e->P, e->i_patch_w, e->i_patch_b, DEP_MISC));
-  RUN(TK_LN_BWD, 0, 0, launch_sum_partials_many(e->ln_tab, s));  // dgamma / dbeta of every LayerNorm: one launch
-  return join_side(c);
+  if (e->ln_tab.n > 0) RUN(TK_LN_BWD, 0, 0, launch_sum_partials_many(e->ln_tab, s));  // dgamma / dbeta of every LayerNorm not yet retired: one launch
+  e->ln_tab.n = 0;
+  MAE_TRY(join_side(c));
+  if (c.ready && c.ready[e->depth]) MAE_HIP(hipEventRecord((hipEvent_t)c.ready[e->depth], s));
+  return 0;
 }
 
 }  // namespace mae
@@ -638,16 +660,17 @@ extern "C" int mae_engine_backward(mae_engine_t* e, const float* params, const v
   return backward_impl(c, pl);
 }
 
-extern "C" int mae_engine_loss_and_grads(mae_engine_t* e, const float* params, const void* wcache, const float* images,
-                                         const float* noise, int32_t batch, int32_t num_keep, float grad_scale, void* workspace,
-                                         int64_t workspace_bytes, float* grads, float* loss_out, int64_t* idx_keep_out,
-                                         int64_t* idx_mask_out, void* stream) {
+static int loss_and_grads_impl(mae_engine_t* e, const float* params, const void* wcache, const float* images, const float* noise,
+                               int32_t batch, int32_t num_keep, float grad_scale, void* workspace, int64_t workspace_bytes, float* grads,
+                               float* loss_out, int64_t* idx_keep_out, int64_t* idx_mask_out, void* const* ready, void* stream,
+                               const char* who) {
   Plan pl;
-  MAE_TRY(check_call(e, params, wcache, batch, num_keep, workspace, workspace_bytes, &pl, "mae_engine_loss_and_grads"));
-  MAE_REQUIRE(images && noise && grads && loss_out, "mae_engine_loss_and_grads: null argument");
-  MAE_REQUIRE(pl.m > 0, "mae_engine_loss_and_grads: nothing is masked");
+  MAE_TRY(check_call(e, params, wcache, batch, num_keep, workspace, workspace_bytes, &pl, who));
+  MAE_REQUIRE(images && noise && grads && loss_out, "%s: null argument", who);
+  MAE_REQUIRE(pl.m > 0, "%s: nothing is masked", who);
   hipStream_t s = (hipStream_t)stream;
   Ctx c{e, params, (const char*)wcache, grads, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
+  c.ready = ready;
   {
     TimerScope ts(e, TK_DATA, 0, (double)pl.Md * 12, s);
     MAE_TRY(launch_mask_from_noise(noise, batch, e->L, num_keep, idx_keep_out, idx_mask_out, c.buf<int32_t>(pl.keep32), c.buf<int32_t>(pl.mask32), s));
@@ -656,6 +679,38 @@ extern "C" int mae_engine_loss_and_grads(mae_engine_t* e, const float* params, c
   MAE_TRY(forward_decoder_impl(c, pl, nullptr));
   RUN(TK_LOSS, 0, pl.Mp * e->P * (8 + c.as), launch_mse_from_images(c.buf<float>(pl.pred), images, c.buf<int32_t>(pl.mask32), batch, pl.m, e->C, e->img, e->p, grad_scale, loss_out, c.buf<>(pl.dpred), e->act, c.buf<float>(pl.loss_scratch), s));
   return backward_impl(c, pl);
+}
+
+extern "C" int mae_engine_loss_and_grads(mae_engine_t* e, const float* params, const void* wcache, const float* images,
+                                         const float* noise, int32_t batch, int32_t num_keep, float grad_scale, void* workspace,
+                                         int64_t workspace_bytes, float* grads, float* loss_out, int64_t* idx_keep_out,
+                                         int64_t* idx_mask_out, void* stream) {
+  return loss_and_grads_impl(e, params, wcache, images, noise, batch, num_keep, grad_scale, workspace, workspace_bytes, grads, loss_out,
+                             idx_keep_out, idx_mask_out, nullptr, stream, "mae_engine_loss_and_grads");
+}
+
+extern "C" int32_t mae_engine_grad_ready_points(const mae_engine_t* e, int64_t* offsets, int32_t max_points) {
+  if (!e) return 0;
+  const int n = e->depth + 1;
+  if (offsets) {
+    for (int j = 0; j < n && j < max_points; ++j) {
+      if (j == 0) offsets[j] = e->params[e->i_dec_mask].offset;
+      else if (j < e->depth) offsets[j] = e->params[e->enc[e->depth - j].ln1_w].offset;
+      else offsets[j] = 0;
+    }
+  }
+  return n;
+}
+
+extern "C" int mae_engine_loss_and_grads_phased(mae_engine_t* e, const float* params, const void* wcache, const float* images,
+                                                const float* noise, int32_t batch, int32_t num_keep, float grad_scale, void* workspace,
+                                                int64_t workspace_bytes, float* grads, float* loss_out, int64_t* idx_keep_out,
+                                                int64_t* idx_mask_out, void* const* ready_events, int32_t num_ready, void* stream) {
+  MAE_REQUIRE(e, "mae_engine_loss_and_grads_phased: null engine");
+  MAE_REQUIRE(ready_events && num_ready == e->depth + 1,
+              "mae_engine_loss_and_grads_phased: need one event slot per gradient-ready point (%d), got %d", e->depth + 1, num_ready);
+  return loss_and_grads_impl(e, params, wcache, images, noise, batch, num_keep, grad_scale, workspace, workspace_bytes, grads, loss_out,
+                             idx_keep_out, idx_mask_out, ready_events, stream, "mae_engine_loss_and_grads_phased");
 }
 
 extern "C" int mae_engine_optimizer_step(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,

@@ -244,11 +244,18 @@ class MaskedAutoencoder(nn.Module):
     def flat_params(self) -> torch.Tensor:
         return self._arena
 
+    GRAD_TAIL = 64  # floats behind the gradients: slot 0 carries the step's loss through the data-parallel all-reduce
+
+    @property
+    def grad_buffer(self) -> torch.Tensor:
+        """Gradient arena plus GRAD_TAIL floats (one allocation, so a bucket can cover gradients and the loss slot)."""
+        if self._grad_arena is None or self._grad_arena.device != self._arena.device:
+            self._grad_arena = torch.zeros(self._engine.trainable_elems + self.GRAD_TAIL, dtype=torch.float32, device=self._arena.device)
+        return self._grad_arena
+
     @property
     def flat_grads(self) -> torch.Tensor:
-        if self._grad_arena is None or self._grad_arena.device != self._arena.device:
-            self._grad_arena = torch.zeros(self._engine.trainable_elems, dtype=torch.float32, device=self._arena.device)
-        return self._grad_arena
+        return self.grad_buffer[:self._engine.trainable_elems]
 
     def _require_cuda(self) -> torch.device:
         dev = self._arena.device
@@ -401,10 +408,22 @@ class MaskedAutoencoder(nn.Module):
         return self._run_forward(images, idx_keep, idx_mask)
 
     # ------------------------------------------------------------------ fused step pieces (used by training.py)
+    def grad_ready_points(self) -> List[int]:
+        """Arena offsets of the backward pass's gradient-ready points, in the order they are reached: reaching point j
+        means ``flat_grads[offsets[j]:]`` is final (decoder first, encoder block 0 / patch projection last)."""
+        n = lib.mae_engine_grad_ready_points(self._engine.handle, None, 0)
+        offs = (C.c_int64 * n)()
+        lib.mae_engine_grad_ready_points(self._engine.handle, offs, n)
+        return list(offs)
+
     def loss_and_grads(self, images: torch.Tensor, noise: torch.Tensor, grad_scale: float = 1.0,
-                       return_indices: bool = False):
+                       return_indices: bool = False, ready_events: Optional[List[Optional[torch.cuda.Event]]] = None,
+                       loss_out: Optional[torch.Tensor] = None):
         """zero_grad + mask + forward + MSE + backward in one native call (src/training/mae.py:45-50 + loss.backward()).
-        Gradients land in ``flat_grads``; returns the device scalar loss (no host sync)."""
+        Gradients land in ``flat_grads``; returns the device scalar loss (no host sync).
+        ``ready_events``: one entry per gradient-ready point (``None`` = skip); each event is recorded on the current
+        stream when its point is reached (the data-parallel step starts that range's all-reduce behind it).
+        ``loss_out``: a 1-element fp32 device tensor to receive the loss (default: a fresh one)."""
         dev = self._require_cuda()
         images = self._check_images(images)
         B, L, k = images.shape[0], self.sequence_length, self.num_keep()
@@ -412,14 +431,20 @@ class MaskedAutoencoder(nn.Module):
             raise ValueError(f"noise must be a contiguous fp32 ({B}, {L}) tensor")
         ws = self._ws(B, k)
         self._ws_generation += 1
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev) if loss_out is None else loss_out
         keep = mask = None
         if return_indices:
             keep = torch.empty(B, k, dtype=torch.int64, device=dev)
             mask = torch.empty(B, L - k, dtype=torch.int64, device=dev)
-        check(lib.mae_engine_loss_and_grads(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images), _ptr(noise),
-                                           B, k, float(grad_scale), _ptr(ws), ws.numel(), _ptr(self.flat_grads), _ptr(loss),
-                                           _ptr(keep), _ptr(mask), _stream(dev)))
+        if ready_events is None:
+            check(lib.mae_engine_loss_and_grads(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images), _ptr(noise),
+                                               B, k, float(grad_scale), _ptr(ws), ws.numel(), _ptr(self.flat_grads), _ptr(loss, torch.float32),
+                                               _ptr(keep), _ptr(mask), _stream(dev)))
+        else:
+            evs = (C.c_void_p * len(ready_events))(*[C.c_void_p(ev.cuda_event) if ev is not None else C.c_void_p(0) for ev in ready_events])
+            check(lib.mae_engine_loss_and_grads_phased(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images),
+                                                      _ptr(noise), B, k, float(grad_scale), _ptr(ws), ws.numel(), _ptr(self.flat_grads),
+                                                      _ptr(loss, torch.float32), _ptr(keep), _ptr(mask), evs, len(ready_events), _stream(dev)))
         return (loss, keep, mask) if return_indices else loss
 
     def named_flat_views(self, flat: torch.Tensor) -> Dict[str, torch.Tensor]:

@@ -166,16 +166,16 @@ def test_forward_features_all_tokens(dev):
 # ------------------------------------------------------------------------------------------------------------------
 # full BASELINE size (ViT-S/8 96px, B=2000): size-independent properties (the oracle would take minutes here)
 # ------------------------------------------------------------------------------------------------------------------
-def test_full_size_properties_vits8_b2000(dev):
-    cfg, B = O.VIT_S8_YAMLDEC, 2000
+def _full_size_properties(dev, cfg, B):
     model = MaskedAutoencoder(*cfg_dicts(cfg, "bf16")).to(dev)
     g = torch.Generator(device=dev).manual_seed(73)
-    images = torch.rand(B, 3, 96, 96, device=dev, generator=g) * 2 - 1
+    images = torch.rand(B, cfg.in_chans, cfg.image_size, cfg.image_size, device=dev, generator=g) * 2 - 1
     noise = torch.rand(B, cfg.sequence_length, device=dev, generator=g)
     loss1, keep, mask = model.loss_and_grads(images, noise, return_indices=True)
     g1 = model.flat_grads.clone()
     # (1) keep U mask is a permutation of the tokens, class token first, noise ascending
     allidx = torch.cat([keep, mask], 1)
+    assert keep.shape[1] == cfg.num_keep()
     assert torch.equal(allidx.sort(1).values, torch.arange(cfg.sequence_length, device=dev).repeat(B, 1))
     assert bool((keep[:, 0] == 0).all())
     nz = noise.clone(); nz[:, 0] = -1
@@ -195,6 +195,17 @@ def test_full_size_properties_vits8_b2000(dev):
     assert rel_err(ga + model.flat_grads, g1) < 2e-2
     # (5) frozen position tables and the unreachable encoder mask token are outside the optimizer range
     assert model.engine.trainable_elems < model.engine.arena_elems
+    assert model.engine.trainable_elems >= sum(torch.Size(s).numel() for n, s in O.param_shapes(cfg).items() if n in O.trainable_names(cfg))
+
+
+def test_full_size_properties_vits8_b2000(dev):
+    _full_size_properties(dev, O.VIT_S8_YAMLDEC, 2000)
+
+
+def test_full_size_properties_vitb16_b512(dev):
+    """BASELINE.json configs[3] at its per-GPU batch (global 4096 over 8 GPUs): K = 768 / 3072, N = 2304 GEMMs, 49- and
+    197-token attention (head dims 64 and 32), 512-wide decoder on the 128 x 128 wgrad tiles."""
+    _full_size_properties(dev, O.VIT_B16_DEC512, 512)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -321,6 +332,31 @@ def test_vits8_dec512_matches_oracle(dev, prec, B, tol_loss, tol_grad):
     num = sum(float((g[n].double().cpu() - gr.double()).pow(2).sum()) for n, gr in grads_ref.items())
     den = sum(float(gr.double().pow(2).sum()) for gr in grads_ref.values())
     assert (num / den) ** 0.5 < tol_grad
+
+
+# BASELINE.json configs[3]: ViT-B/16 224 px + decoder 512 x 8 x 16 heads (k = 49, m = 148, L = 197, P = 768)
+@pytest.mark.parametrize("prec,B,tol_loss,tol_grad", [("fp32", 2, 1e-4, 2e-4), ("bf16", 3, 5e-3, 5e-2)])
+def test_vitb16_matches_oracle(dev, prec, B, tol_loss, tol_grad):
+    cfg, r = O.VIT_B16_DEC512, 0.75
+    assert (cfg.sequence_length, cfg.num_keep(r), cfg.patch_dim) == (197, 49, 768)
+    assert abs(O.flops_per_image_step(cfg) / 1e9 - 57.5245) < 1e-3
+    model, params = build(cfg, prec, dev, r)
+    images = O.synthetic_images(B, cfg)
+    noise = O.make_noise(B, cfg.sequence_length, torch.Generator().manual_seed(13))
+    loss_ref, grads_ref, aux = O.loss_and_grads(params, cfg, images, noise, r, bf16=(prec == "bf16"))
+    loss, keep, mask = model.loss_and_grads(images.to(dev), noise.to(dev), return_indices=True)
+    assert torch.equal(keep.cpu(), aux["idx_keep"]) and torch.equal(mask.cpu(), aux["idx_mask"])
+    assert abs(loss.item() - loss_ref.item()) <= tol_loss * abs(loss_ref.item())
+    g = model.named_flat_views(model.flat_grads)
+    num = sum(float((g[n].double().cpu() - gr.double()).pow(2).sum()) for n, gr in grads_ref.items())
+    den = sum(float(gr.double().pow(2).sum()) for gr in grads_ref.values())
+    assert (num / den) ** 0.5 < tol_grad
+    if prec == "fp32":
+        for n, gr in grads_ref.items():
+            assert rel_err(g[n], gr) < 5e-4, n
+        x_enc = model.forward_encoder(images.to(dev), keep)
+        assert rel_err(x_enc, aux["x_encoded"]) < 1e-4
+        assert rel_err(model.forward_decoder(x_enc, keep, mask), aux["x_pred"]) < 1e-4
 
 
 # Other geometries than the reference's 96 px / patch 8 / 3 channels: the kernels are not specialised to them

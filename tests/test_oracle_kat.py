@@ -24,6 +24,10 @@ def test_vits8_census_and_flops_match_baseline_md():
     c = O.param_census(O.VIT_S8_DEC512)
     assert c["total"] == 34_405_824 and c["trainable"] == 34_275_904
     assert abs(O.flops_per_image_step(O.VIT_S8_DEC512) / 1e9 - 16.2442) < 1e-4
+    c = O.param_census(O.VIT_B16_DEC512)  # BASELINE.json configs[3]; BASELINE.md section 3 last row
+    assert c["trainable"] == 111_656_448
+    assert (O.VIT_B16_DEC512.sequence_length, O.VIT_B16_DEC512.num_keep(), O.VIT_B16_DEC512.patch_dim) == (197, 49, 768)
+    assert abs(O.flops_per_image_step(O.VIT_B16_DEC512) / 1e9 - 57.5245) < 1e-4
 
 
 def test_state_dict_names_follow_survey_8b():
