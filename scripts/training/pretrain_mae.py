@@ -40,36 +40,17 @@ def parse_args(argv=None):
 
 
 def save_checkpoint(path: Path, module: MAEPretrainModule, epoch: int, weights_only: bool = False, extra=None) -> None:
-    """Lightning-shaped checkpoint: ``state_dict`` keys carry the ``model.`` prefix the reference's loaders sniff
-    (scripts/training/train_mae.py:105-109)."""
-    ckpt = {"epoch": epoch, "global_step": module.global_step,
-            "state_dict": {f"model.{k}": v.detach().cpu().clone() for k, v in module.model.state_dict().items()}}
-    if not weights_only:
-        opt = module.optimizer_state_dict()
-        ckpt["optimizer_states"] = [{"step": opt["step"],
-                                     "exp_avg": {k: v.cpu().clone() for k, v in opt["exp_avg"].items()},
-                                     "exp_avg_sq": {k: v.cpu().clone() for k, v in opt["exp_avg_sq"].items()}}]
-    if extra:
-        ckpt.update(extra)
+    """Lightning-shaped checkpoint (MAEPretrainModule.checkpoint_dict), written atomically."""
     tmp = path.with_suffix(path.suffix + ".tmp")
-    torch.save(ckpt, tmp)
+    torch.save(module.checkpoint_dict(epoch, weights_only=weights_only, extra=extra), tmp)
     os.replace(tmp, path)
 
 
-def load_checkpoint(path: str, module: MAEPretrainModule) -> int:
+def load_checkpoint(path: str, module: MAEPretrainModule):
+    """Returns (epoch to continue with, the checkpoint dict).  Files are opened with the safe loader only; a reference
+    Lightning checkpoint whose hyper-parameters need unpickling is refused by it and reported as such."""
     ckpt = torch.load(path, map_location="cpu", weights_only=True)
-    sd = ckpt.get("state_dict", ckpt)
-    sd = {k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()}
-    module.model.load_state_dict(sd, strict=True)
-    if "optimizer_states" in ckpt:
-        st = ckpt["optimizer_states"][0]
-        m, v, _ = module._opt_state()
-        mv, vv = module.model.named_flat_views(m), module.model.named_flat_views(v)
-        for k in mv:
-            mv[k].copy_(st["exp_avg"][k]); vv[k].copy_(st["exp_avg_sq"][k])
-        module._opt_steps = int(st["step"])
-    module.global_step = int(ckpt.get("global_step", 0))
-    return int(ckpt.get("epoch", -1)) + 1
+    return module.load_checkpoint_dict(ckpt), ckpt
 
 
 def main(argv=None):
@@ -98,7 +79,7 @@ def main(argv=None):
         print(f"Saved config snapshot to: {output_dir / 'config.yaml'}")
 
     module = MAEPretrainModule(model_cfg=model_cfg, training_cfg=pre_cfg).to(dev)
-    start_epoch = load_checkpoint(args.resume_from, module) if args.resume_from else 0
+    start_epoch, resumed = load_checkpoint(args.resume_from, module) if args.resume_from else (0, {})
     module = module.to(dev)
     L = module.model.sequence_length
     global_batch = int(pre_cfg["batch_size"])
@@ -106,12 +87,18 @@ def main(argv=None):
         raise SystemExit(f"batch_size {global_batch} must be divisible by the number of GPUs {world}")
     train_batches, val_batches = get_pretrain_batches(cfg, dev, synthetic_images=args.synthetic_images, seed=SEED)
 
+    # resume bookkeeping: best validation loss so far (kept in last.ckpt, else read from the best.ckpt next to it)
     best_val, log_path = float("inf"), output_dir / "logs" / "metrics.jsonl"
+    if args.resume_from:
+        best_val = float(resumed.get("best_val_loss", best_val))
+        best_path = Path(args.resume_from).with_name("best.ckpt")
+        if best_val == float("inf") and best_path.exists():
+            best_val = float(torch.load(best_path, map_location="cpu", weights_only=True).get("val_loss", best_val))
     total_epochs = int(pre_cfg["total_epochs"]) if args.max_epochs is None else min(int(pre_cfg["total_epochs"]), start_epoch + args.max_epochs)
     for epoch in range(start_epoch, total_epochs):
         module.current_epoch = epoch
         module.on_train_epoch_start()
-        t0, seen, loss_sum = time.perf_counter(), 0, torch.zeros(1, device=dev)
+        t0, seen, steps, loss_sum = time.perf_counter(), 0, 0, torch.zeros(1, device=dev)
         for step, images in enumerate(train_batches(epoch)):
             if args.max_steps_per_epoch is not None and step >= args.max_steps_per_epoch:
                 break
@@ -120,20 +107,23 @@ def main(argv=None):
                 continue  # ragged tail of the epoch cannot be sharded evenly; the reference (1 GPU) has no such case
             noise = mdist.global_noise(gb, L, SEED, module.global_step, dev)
             loss = module.fused_training_step(mdist.shard_rows(images, rank, world), mdist.shard_rows(noise, rank, world))
-            loss_sum += loss
+            loss_sum += loss  # already the global mean (it rides through the gradient all-reduce)
             seen += gb
-        steps = max(1, module.global_step - getattr(module, "_epoch_step0", 0))
-        module._epoch_step0 = module.global_step
-        # validation (masked-reconstruction MSE, no grad)
-        val_sum, val_n = torch.zeros(1, device=dev), 0
+            steps += 1
+        # validation (masked-reconstruction MSE, no grad): rank r takes rows r::world of every batch, the sums are reduced
+        val = torch.zeros(2, device=dev, dtype=torch.float64)  # [sum of per-image losses, images]
         with torch.no_grad():
             for images in val_batches():
-                imgs = mdist.shard_rows(images, rank, world) if images.shape[0] % world == 0 else images
+                imgs = images[rank::world].contiguous()
+                if imgs.shape[0] == 0:
+                    continue
                 preds, targets = module.model(imgs)
-                val_sum += torch.nn.functional.mse_loss(preds, targets) * imgs.shape[0]
-                val_n += imgs.shape[0]
-        train_loss = float(loss_sum.item()) / steps
-        val_loss = float(val_sum.item()) / max(1, val_n)
+                val[0] += torch.nn.functional.mse_loss(preds, targets).double() * imgs.shape[0]
+                val[1] += imgs.shape[0]
+        if world > 1:
+            torch.distributed.all_reduce(val)
+        train_loss = float(loss_sum.item()) / max(1, steps)
+        val_loss = float(val[0].item()) / max(1.0, float(val[1].item()))
         dt = time.perf_counter() - t0
         if rank == 0:
             rec = dict(epoch=epoch, train_loss=train_loss, val_loss=val_loss, lr=module.current_lr(), mask_ratio=module.model.mask_ratio,
@@ -141,10 +131,10 @@ def main(argv=None):
             with open(log_path, "a") as f:
                 f.write(json.dumps(rec) + "\n")
             print(json.dumps(rec))
-            save_checkpoint(ckpt_dir / "last.ckpt", module, epoch)
             if val_loss < best_val:
                 best_val = val_loss
-                save_checkpoint(ckpt_dir / "best.ckpt", module, epoch, extra={"val_loss": val_loss})
+                save_checkpoint(ckpt_dir / "best.ckpt", module, epoch, extra={"val_loss": val_loss, "best_val_loss": best_val})
+            save_checkpoint(ckpt_dir / "last.ckpt", module, epoch, extra={"val_loss": val_loss, "best_val_loss": best_val})
             if (epoch + 1) % 25 == 0:
                 save_checkpoint(ckpt_dir / f"epoch-epoch={epoch:03d}.ckpt", module, epoch, weights_only=True)
     if rank == 0:

@@ -1,5 +1,7 @@
 """MAEPretrainModule: the reference's ``src/training/mae.py`` (lines 14-83) without Lightning, plus the fused
-data-parallel step (native loss+grads -> one RCCL all-reduce -> native clip+AdamW).
+data-parallel step: native loss+grads whose backward pass reports gradient-ready points -> bucketed all-reduce of the
+flat gradient arena over RCCL, started on a side stream while the rest of the backward pass still runs -> native
+global-norm clip + AdamW (which needs the WHOLE reduced gradient first: scripts/training/pretrain_mae.py:124-125).
 
 Step semantics kept from the reference:
   * loss = MSELoss(preds, targets)                                          src/training/mae.py:40,48
@@ -12,7 +14,9 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Any, Dict, Optional
+import os
+import warnings
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 from torch import nn
@@ -58,6 +62,12 @@ class MAEPretrainModule(nn.Module):
         self._exp_avg_sq: Optional[torch.Tensor] = None
         self._stats: Optional[torch.Tensor] = None
         self._opt_steps = 0
+        # data-parallel exchange: gradient buckets (arena ranges, in the order the backward pass finishes them)
+        self.bucket_bytes = int(float(os.environ.get("MAE_DP_BUCKET_MB", "24")) * (1 << 20))
+        self.overlap_exchange = os.environ.get("MAE_DP_OVERLAP", "1") != "0"
+        self._buckets: Optional[List[Tuple[int, int, int]]] = None   # (ready point, begin, end) in floats of the grad buffer
+        self._bucket_events: Optional[List[Optional[torch.cuda.Event]]] = None
+        self._comm_stream: Optional[torch.cuda.Stream] = None
 
     # ---- Lightning-shaped surface --------------------------------------------------------------
     def log(self, name: str, value, **_kw) -> None:
@@ -122,25 +132,169 @@ class MAEPretrainModule(nn.Module):
         model.mark_weights_fresh()  # the native step refreshed the operand copies itself
         return stats
 
+    # ---- data-parallel gradient exchange -------------------------------------------------------------
+    def gradient_buckets(self) -> List[Tuple[int, int, int]]:
+        """Ranges of the gradient buffer to all-reduce, in the order the backward pass finishes them: consecutive
+        gradient-ready points (decoder, encoder block depth-1, ..., block 0 + patch projection) are merged until a bucket
+        holds at least ``bucket_bytes``.  The first bucket also covers the loss slot behind the gradients, so the
+        global mean loss rides along without a collective of its own.  The buckets tile the whole buffer exactly."""
+        if self._buckets is None:
+            model = self.model
+            n = model.engine.trainable_elems
+            points = model.grad_ready_points()
+            buckets, end = [], n + 1  # slot n carries the loss
+            for j, off in enumerate(points):
+                last = j == len(points) - 1
+                if last or (end - off) * 4 >= self.bucket_bytes:
+                    if off < end:
+                        buckets.append((j, off, end))
+                    end = off
+            assert end == 0 and sum(b[2] - b[1] for b in buckets) == n + 1
+            self._buckets = buckets
+        return self._buckets
+
+    def _exchange_state(self, dev):
+        if self._bucket_events is None or self._comm_stream is None or self._comm_stream.device != dev:
+            npts = len(self.model.grad_ready_points())
+            evs: List[Optional[torch.cuda.Event]] = [None] * npts
+            for j, _b, _e in self.gradient_buckets():
+                evs[j] = torch.cuda.Event()
+                evs[j].record(torch.cuda.current_stream(dev))  # torch creates the HIP event lazily: force it now
+            self._bucket_events = evs
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        return self._bucket_events, self._comm_stream
+
     def fused_training_step(self, images: torch.Tensor, noise: Optional[torch.Tensor] = None, lr: Optional[float] = None,
                             process_group=None) -> torch.Tensor:
-        """One whole pretrain step.  With torch.distributed initialised the local gradients (already divided by
-        world size) are summed with ONE all-reduce over RCCL before the global-norm clip."""
+        """One whole pretrain step.  With torch.distributed initialised every rank computes its rows of the global batch
+        with the loss gradient pre-divided by the world size, the gradient buckets are summed over RCCL as the backward
+        pass finishes them (on a side stream, behind the engine's gradient-ready events), and every rank then applies
+        the same global-norm clip + AdamW.  Returns the GLOBAL mean loss as a device scalar (no host sync)."""
         model = self.model
         dev = model._require_cuda()
-        world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            world = torch.distributed.get_world_size(process_group)
+        dist = torch.distributed
+        world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         if noise is None:
             noise = torch.rand(images.shape[0], model.sequence_length, device=dev)
-        loss = model.loss_and_grads(images, noise, grad_scale=1.0 / world)
-        if world > 1:
-            torch.distributed.all_reduce(model.flat_grads, op=torch.distributed.ReduceOp.SUM, group=process_group)
+        if world == 1:
+            loss = model.loss_and_grads(images, noise)
+        else:
+            n = model.engine.trainable_elems
+            buf = model.grad_buffer
+            loss_slot = buf[n:n + 1]
+            if self.overlap_exchange:
+                events, comm = self._exchange_state(dev)
+                main = torch.cuda.current_stream(dev)
+                comm.wait_stream(main)  # the previous step's optimizer has read the buffer before it is reduced into again
+                model.loss_and_grads(images, noise, grad_scale=1.0 / world, ready_events=events, loss_out=loss_slot)
+                works = []
+                with torch.cuda.stream(comm):
+                    for j, b, e in self.gradient_buckets():
+                        comm.wait_event(events[j])
+                        works.append(dist.all_reduce(buf[b:e], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
+                    for w in works:
+                        w.wait()
+                main.wait_stream(comm)
+            else:  # one blocking collective after the whole backward pass
+                model.loss_and_grads(images, noise, grad_scale=1.0 / world, loss_out=loss_slot)
+                dist.all_reduce(buf[:n + 1], op=dist.ReduceOp.SUM, group=process_group)
+            loss = loss_slot / world  # sum of the ranks' local means / world = global mean (equal local batches)
         self.optimizer_step(lr)
         self.global_step += 1
         self.log("train_loss", loss)
         return loss
 
+    # ---- optimizer state in the layout Lightning checkpoints carry (torch.optim.AdamW.state_dict()) ------------------
+    def _named_param_index(self) -> List[Tuple[int, str, bool]]:
+        """(index in self.parameters() order, state_dict name, has optimizer state) -- the reference hands every
+        parameter to AdamW (src/training/mae.py:62); only those that receive a gradient get state."""
+        trainable = set(self.model.named_flat_views(self.model.flat_grads))
+        return [(i, n, n in trainable) for i, (n, _p) in enumerate(self.model.named_parameters())]
+
     def optimizer_state_dict(self) -> Dict[str, Any]:
         m, v, _ = self._opt_state()
-        return {"step": self._opt_steps, "exp_avg": self.model.named_flat_views(m), "exp_avg_sq": self.model.named_flat_views(v)}
+        mv, vv = self.model.named_flat_views(m), self.model.named_flat_views(v)
+        state = {}
+        if self._opt_steps > 0:
+            for i, name, has in self._named_param_index():
+                if has:
+                    state[i] = {"step": torch.tensor(float(self._opt_steps)), "exp_avg": mv[name].detach().cpu().clone(),
+                                "exp_avg_sq": vv[name].detach().cpu().clone()}
+        group = {"lr": self.current_lr(), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True, "initial_lr": self.effective_lr,
+                 "params": [i for i, _n, _h in self._named_param_index()]}
+        return {"state": state, "param_groups": [group]}
+
+    def lr_scheduler_state_dict(self) -> Dict[str, Any]:
+        """LambdaLR.state_dict() as Lightning stores it (the lambda itself is not picklable and is saved as None)."""
+        return {"base_lrs": [self.effective_lr], "last_epoch": self.current_epoch, "verbose": False,
+                "_step_count": self.current_epoch + 1, "_get_lr_called_within_step": False, "_last_lr": [self.current_lr()],
+                "lr_lambdas": [None]}
+
+    def load_optimizer_state_dict(self, st: Dict[str, Any]) -> bool:
+        """Accepts torch.optim.AdamW.state_dict() (what a reference Lightning ``last.ckpt`` holds, indexed in
+        ``parameters()`` order) and this repository's round-1 layout ({step, exp_avg{name}, exp_avg_sq{name}}).
+        Unknown layouts: weights-only resume with a warning.  Returns True when the state was restored."""
+        m, v, _ = self._opt_state()
+        mv, vv = self.model.named_flat_views(m), self.model.named_flat_views(v)
+        try:
+            if "state" in st and "param_groups" in st:
+                by_index = {i: n for i, n, has in self._named_param_index() if has}
+                if not st["state"]:
+                    m.zero_(); v.zero_(); self._opt_steps = 0
+                    return True
+                missing = [n for i, n in by_index.items() if i not in st["state"]]
+                if missing:
+                    raise KeyError(f"no optimizer state for {missing[:3]}...")
+                steps = set()
+                for i, n in by_index.items():
+                    e = st["state"][i]
+                    if tuple(e["exp_avg"].shape) != tuple(mv[n].shape):
+                        raise ValueError(f"optimizer state {i} has shape {tuple(e['exp_avg'].shape)}, parameter {n} {tuple(mv[n].shape)}")
+                    mv[n].copy_(e["exp_avg"]); vv[n].copy_(e["exp_avg_sq"])
+                    steps.add(int(float(e["step"])))
+                if len(steps) != 1:
+                    raise ValueError(f"per-parameter step counts differ: {sorted(steps)[:4]}")
+                self._opt_steps = steps.pop()
+                return True
+            if "exp_avg" in st and "exp_avg_sq" in st:
+                for k in mv:
+                    mv[k].copy_(st["exp_avg"][k]); vv[k].copy_(st["exp_avg_sq"][k])
+                self._opt_steps = int(st["step"])
+                return True
+            raise KeyError(f"unknown optimizer state layout with keys {sorted(st)[:6]}")
+        except (KeyError, ValueError, TypeError, IndexError) as exc:
+            warnings.warn(f"optimizer state not restored ({exc}); resuming from the weights only", RuntimeWarning)
+            m.zero_(); v.zero_(); self._opt_steps = 0
+            return False
+
+    def checkpoint_dict(self, epoch: int, weights_only: bool = False, extra: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
+        """A Lightning-shaped checkpoint: ``state_dict`` keys carry the ``model.`` prefix the reference's loaders sniff
+        (scripts/training/train_mae.py:105-109); ``optimizer_states`` / ``lr_schedulers`` / ``hyper_parameters`` /
+        ``pytorch-lightning_version`` / ``loops`` are the keys ``Trainer.fit(ckpt_path=...)`` reads (uv.lock:1772-1773)."""
+        ckpt: Dict[str, Any] = {
+            "epoch": epoch, "global_step": self.global_step, "pytorch-lightning_version": "2.5.6",
+            "state_dict": {f"model.{k}": t.detach().cpu().clone() for k, t in self.model.state_dict().items()},
+            "loops": {"fit_loop": {"epoch_progress": {"current": {"completed": epoch + 1, "processed": epoch + 1, "ready": epoch + 1, "started": epoch + 1}}}},
+            "callbacks": {},
+            "hyper_parameters": {"model_cfg": self.hparams["model_cfg"], "training_cfg": self.hparams["training_cfg"]},
+        }
+        if not weights_only:
+            ckpt["optimizer_states"] = [self.optimizer_state_dict()]
+            ckpt["lr_schedulers"] = [self.lr_scheduler_state_dict()]
+        if extra:
+            ckpt.update(extra)
+        return ckpt
+
+    def load_checkpoint_dict(self, ckpt: Dict[str, Any]) -> int:
+        """Restore weights (+ optimizer state when present) from a checkpoint of this repository or of the reference's
+        Lightning Trainer; returns the epoch to continue with."""
+        sd = ckpt.get("state_dict", ckpt)
+        sd = {k[len("model."):] if k.startswith("model.") else k: t for k, t in sd.items()}
+        self.model.load_state_dict(sd, strict=True)
+        if ckpt.get("optimizer_states"):
+            self.load_optimizer_state_dict(ckpt["optimizer_states"][0])
+        self.global_step = int(ckpt.get("global_step", 0))
+        return int(ckpt.get("epoch", -1)) + 1
+

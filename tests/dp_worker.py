@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""One data-parallel rank of the PRODUCT step (MAEPretrainModule.fused_training_step over libmae_hip.so), started as a
+fresh child process by tests/test_gpu_dp.py (and usable by hand).  Every rank uses cuda:0 (a one-GPU box) and the gloo
+backend; rank r takes rows [r*B/W, (r+1)*B/W) of the seeded global images and noise, runs `--steps` whole steps and
+saves its final parameters, losses and first-step masks.  With --world 1 it is the single-process full-batch step.
+
+    python tests/dp_worker.py --rank 0 --world 2 --port 29511 --out /tmp/x --config micro --precision fp32
+"""
+import argparse
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, required=True)
+    ap.add_argument("--port", type=int, default=29511)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--config", default="micro", choices=["micro", "vits8"])
+    ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--global-batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=2)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ssrl_vit_mae_jepa_amd import MAEPretrainModule
+    from ssrl_vit_mae_jepa_amd import dist as mdist
+
+    if a.world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world), LOCAL_RANK="0")
+        dist.init_process_group("gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    if a.config == "micro":
+        general = dict(image_size=32, patch_size=8, in_chans=3, mask_ratio=0.75)
+        encoder, decoder = dict(embed_dim=48, depth=3, num_heads=2), dict(decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2)
+    else:
+        general = dict(image_size=96, patch_size=8, in_chans=3, mask_ratio=0.75)
+        encoder, decoder = dict(embed_dim=384, depth=12, num_heads=6), dict(decoder_embed_dim=192, decoder_depth=2, decoder_num_heads=6)
+    general["engine_precision"] = a.precision
+    tcfg = dict(mask_ratio_start=0.75, mask_ratio_end=0.75, mask_ramp_epochs=5, total_epochs=800, warmup_epochs=20,
+                batch_size=2000, base_learning_rate=1.5e-4, weight_decay=0.05)
+    module = MAEPretrainModule(dict(general=general, encoder=encoder, decoder=decoder), tcfg)
+    module.model._init_weights(seed=73)  # identical parameters on every rank
+    with torch.no_grad():  # non-zero biases / LayerNorm affine so every gradient term is exercised
+        g = torch.Generator().manual_seed(7)
+        for n, p in module.model.named_parameters():
+            if p.requires_grad and p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    module = module.to(dev)
+    module.on_train_epoch_start()
+    model = module.model
+    B, L = a.global_batch, model.sequence_length
+    gi = torch.Generator().manual_seed(100)
+    images = (torch.rand(B, 3, general["image_size"], general["image_size"], generator=gi) * 2 - 1).to(dev)
+    losses, keep0 = [], None
+    for step in range(a.steps):
+        noise = mdist.global_noise(B, L, 73, step, dev)
+        my_images, my_noise = mdist.shard_rows(images, a.rank, a.world), mdist.shard_rows(noise, a.rank, a.world)
+        if step == 0:
+            keep0 = model.random_token_mask(my_images.shape[0], my_noise)[0].cpu()
+        losses.append(module.fused_training_step(my_images, my_noise).clone())
+    torch.cuda.synchronize()
+    out = {"params": model.flat_params.detach().cpu(), "losses": torch.cat(losses).cpu(), "keep0": keep0,
+           "stats": module._stats.cpu(), "buckets": module.gradient_buckets() if a.world > 1 else [],
+           "overlap": module.overlap_exchange}
+    torch.save(out, f"{a.out}/w{a.world}_r{a.rank}.pt")
+    if a.world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

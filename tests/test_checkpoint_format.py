@@ -1,0 +1,97 @@
+"""Checkpoint wire format (CPU, no GPU): the optimizer state travels as torch.optim.AdamW.state_dict() indexed in
+``parameters()`` order, the layout a reference Lightning ``last.ckpt`` holds (scripts/training/pretrain_mae.py:84-100 ->
+``trainer.fit(..., ckpt_path=args.resume_from)``, :126), next to ``lr_schedulers`` / ``hyper_parameters`` /
+``pytorch-lightning_version`` / ``loops``.  No reference checkpoint exists offline: the Lightning-shaped dict is hand-built
+from a real torch AdamW over the same parameter list."""
+import warnings
+
+import pytest
+import torch
+
+from ssrl_vit_mae_jepa_amd import MAEPretrainModule
+
+MODEL = dict(general=dict(image_size=32, patch_size=8, in_chans=3), encoder=dict(embed_dim=48, depth=2, num_heads=2),
+             decoder=dict(decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2))
+TRAIN = dict(batch_size=512, base_learning_rate=1.5e-4, weight_decay=0.05, warmup_epochs=2, total_epochs=10)
+NO_STATE = ("encoder.mask_token", "encoder.vit.pos_embed", "decoder.decoder_pos_embed")  # no gradient on the MAE path
+
+
+def _reference_shaped_checkpoint(module, seed=3):
+    """What Lightning would save for this module: a real AdamW over module.parameters() stepped once with synthetic grads."""
+    g = torch.Generator().manual_seed(seed)
+    named = list(module.model.named_parameters())
+    shadow = [torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad) for _n, p in named]
+    opt = torch.optim.AdamW(shadow, lr=module.effective_lr, weight_decay=module.weight_decay)
+    for (n, _p), q in zip(named, shadow):
+        if n not in NO_STATE:
+            q.grad = torch.randn(q.shape, generator=g)
+    opt.step(); opt.step()
+    return {"epoch": 4, "global_step": 2, "pytorch-lightning_version": "2.5.6",
+            "state_dict": {f"model.{n}": q.detach().clone() for (n, _p), q in zip(named, shadow)},
+            "optimizer_states": [opt.state_dict()], "lr_schedulers": [{"last_epoch": 5}], "loops": {}, "callbacks": {},
+            "hyper_parameters": {"model_cfg": MODEL, "training_cfg": TRAIN}}, opt, [n for n, _p in named]
+
+
+def test_resume_from_a_lightning_shaped_checkpoint():
+    module = MAEPretrainModule(MODEL, TRAIN)
+    ckpt, opt, names = _reference_shaped_checkpoint(module)
+    assert module.load_checkpoint_dict(ckpt) == 5 and module.global_step == 2 and module._opt_steps == 2
+    mv = module.model.named_flat_views(module._exp_avg)
+    vv = module.model.named_flat_views(module._exp_avg_sq)
+    st = opt.state_dict()["state"]
+    for i, n in enumerate(names):
+        if n in NO_STATE:
+            assert i not in st and n not in mv
+        else:
+            assert torch.equal(mv[n], st[i]["exp_avg"]) and torch.equal(vv[n], st[i]["exp_avg_sq"])
+    sd = module.model.state_dict()
+    assert all(torch.equal(sd[n], ckpt["state_dict"][f"model.{n}"]) for n in names)
+
+
+def test_our_checkpoint_loads_into_a_torch_adamw_and_round_trips():
+    module = MAEPretrainModule(MODEL, TRAIN)
+    ckpt, _opt, names = _reference_shaped_checkpoint(module)
+    module.load_checkpoint_dict(ckpt)
+    module.current_epoch = 4
+    ours = module.checkpoint_dict(epoch=4)
+    assert set(ours) >= {"epoch", "global_step", "pytorch-lightning_version", "state_dict", "loops", "optimizer_states", "lr_schedulers", "hyper_parameters"}
+    assert all(k.startswith("model.") for k in ours["state_dict"]) and ours["hyper_parameters"]["training_cfg"] == TRAIN
+    # the reference Trainer's side: optimizer = AdamW(self.parameters(), ...); optimizer.load_state_dict(ckpt["optimizer_states"][0])
+    shadow = [torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad) for _n, p in module.model.named_parameters()]
+    opt2 = torch.optim.AdamW(shadow, lr=1.0, weight_decay=0.0)
+    opt2.load_state_dict(ours["optimizer_states"][0])
+    st2, st1 = opt2.state_dict(), ckpt["optimizer_states"][0]
+    assert st2["param_groups"][0]["params"] == list(range(len(names))) and st2["param_groups"][0]["weight_decay"] == 0.05
+    assert set(st2["state"]) == set(st1["state"])
+    for i in st1["state"]:
+        assert torch.equal(st2["state"][i]["exp_avg"], st1["state"][i]["exp_avg"]) and float(st2["state"][i]["step"]) == 2.0
+    # survives the safe loader and a second load
+    import io
+    f = io.BytesIO(); torch.save(ours, f); f.seek(0)
+    again = torch.load(f, weights_only=True)
+    m2 = MAEPretrainModule(MODEL, TRAIN)
+    assert m2.load_checkpoint_dict(again) == 5 and torch.equal(m2._exp_avg, module._exp_avg) and m2._opt_steps == 2
+    assert again["lr_schedulers"][0]["last_epoch"] == 4 and again["lr_schedulers"][0]["base_lrs"] == [module.effective_lr]
+
+
+def test_round1_layout_and_unknown_layouts():
+    module = MAEPretrainModule(MODEL, TRAIN)
+    m, v, _ = module._opt_state()
+    for t in module.model.named_flat_views(m).values():  # the 64-element alignment padding between tensors stays zero
+        t.normal_()
+    for t in module.model.named_flat_views(v).values():
+        t.uniform_()
+    old = {"step": 7, "exp_avg": {k: t.clone() for k, t in module.model.named_flat_views(m).items()},
+           "exp_avg_sq": {k: t.clone() for k, t in module.model.named_flat_views(v).items()}}
+    keep = m.clone()
+    m.zero_(); v.zero_()
+    assert module.load_optimizer_state_dict(old) and module._opt_steps == 7 and torch.equal(module._exp_avg, keep)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert not module.load_optimizer_state_dict({"something": "else"})
+    assert w and "weights only" in str(w[0].message) and module._opt_steps == 0 and float(module._exp_avg.abs().sum()) == 0.0
+    # a torch-shaped state for a different model: refused with a warning, never a KeyError
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert not module.load_optimizer_state_dict({"state": {0: {"step": torch.tensor(1.0), "exp_avg": torch.zeros(3), "exp_avg_sq": torch.zeros(3)}}, "param_groups": [{}]})
+    assert w

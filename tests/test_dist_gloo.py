@@ -74,6 +74,55 @@ def test_two_rank_step_equals_single_process_step(tmp_path):
     assert torch.allclose(r0["p"], params["decoder.decoder_pred.weight"], rtol=1e-4, atol=1e-6) and torch.equal(r0["p"], r1["p"])
 
 
+def _bucket_worker(rank, world, port, out_dir):
+    """The product's bucket plan (MAEPretrainModule.gradient_buckets, host logic over the engine's gradient-ready points)
+    driven over gloo on a CPU buffer: bucketed async all-reduces in backward order == one all-reduce of the whole buffer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MAE_DP_BUCKET_MB="0.05")
+    torch.set_num_threads(2)
+    from ssrl_vit_mae_jepa_amd import MAEPretrainModule
+    from ssrl_vit_mae_jepa_amd import dist as mdist
+    mdist.init_from_env(backend="gloo")
+    module = MAEPretrainModule(dict(general=dict(image_size=32, patch_size=8), encoder=dict(embed_dim=48, depth=4, num_heads=2),
+                                    decoder=dict(decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2)), {})
+    n = module.model.engine.trainable_elems
+    buckets = module.gradient_buckets()
+    g = torch.Generator().manual_seed(1000 + rank)
+    buf = torch.randn(n + module.model.GRAD_TAIL, generator=g)
+    whole = buf.clone()
+    works = [dist.all_reduce(buf[b:e], async_op=True) for _j, b, e in buckets]
+    for w in works:
+        w.wait()
+    dist.all_reduce(whole[:n + 1])
+    torch.save({"bucketed": buf, "whole": whole, "buckets": buckets, "n": n}, f"{out_dir}/b{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_plan_tiles_the_arena_and_equals_one_allreduce(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "b0.pt"), torch.load(tmp_path / "b1.pt")
+    n, buckets = r0["n"], r0["buckets"]
+    assert buckets == r1["buckets"] and len(buckets) >= 3
+    assert buckets[0][2] == n + 1 and buckets[-1][1] == 0                           # loss slot in the first bucket; ends at 0
+    assert all(x[1] == y[2] for x, y in zip(buckets, buckets[1:]))                  # contiguous, in backward order
+    assert [x[0] for x in buckets] == sorted(x[0] for x in buckets)                 # ready points are reached in this order
+    assert torch.equal(r0["bucketed"][:n + 1], r0["whole"][:n + 1]) and torch.equal(r0["bucketed"][:n + 1], r1["bucketed"][:n + 1])
+
+
+def test_gradient_ready_points_follow_the_arena_layout():
+    from ssrl_vit_mae_jepa_amd import MaskedAutoencoder
+    model = MaskedAutoencoder(dict(image_size=32, patch_size=8), dict(embed_dim=48, depth=3, num_heads=2),
+                              dict(decoder_embed_dim=64, decoder_depth=2, decoder_num_heads=2))
+    off = {name: o for name, o, _n, _s, _f in model.engine.table}
+    pts = model.grad_ready_points()
+    assert pts == [off["decoder.mask_token"], off["encoder.vit.blocks.2.norm1.weight"], off["encoder.vit.blocks.1.norm1.weight"], 0]
+    # everything the decoder owns lies behind point 0, the encoder's final norm right in front of it
+    assert all(off[n] >= pts[0] for n in off if n.startswith("decoder.") and n != "decoder.decoder_pos_embed")
+    assert pts[1] < off["encoder.vit.norm.weight"] < pts[0]
+
+
 def test_shard_rows_rejects_ragged_batches():
     from ssrl_vit_mae_jepa_amd import dist as mdist
     with pytest.raises(ValueError):

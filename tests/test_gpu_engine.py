@@ -5,6 +5,7 @@ is our restatement, pinned only by the reference's structure known-answers.
 Tolerances (north_star): mask indices bit-exact; fp32 engine loss within 1e-4 relative of the fp32 oracle; the bf16
 engine is compared with the oracle's bf16-operand emulation (loss 5e-3 relative) and with the fp32 oracle (3e-2)."""
 import copy
+import json
 
 import pytest
 import torch
@@ -252,7 +253,12 @@ def test_pretrain_cli_synthetic_run_and_resume(dev, tmp_path, monkeypatch):
     assert (out / "checkpoints" / "last.ckpt").exists() and (out / "checkpoints" / "best.ckpt").exists()
     ck = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
     assert ck["epoch"] == 1 and all(k.startswith("model.") for k in ck["state_dict"])
-    assert "model.encoder.vit.blocks.0.attn.qkv.weight" in ck["state_dict"] and ck["optimizer_states"][0]["step"] == ck["global_step"]
+    assert "model.encoder.vit.blocks.0.attn.qkv.weight" in ck["state_dict"]
+    opt = ck["optimizer_states"][0]  # torch.optim.AdamW.state_dict() layout, indexed in parameters() order
+    assert opt["param_groups"][0]["params"] == list(range(len(ck["state_dict"])))
+    assert all(float(st["step"]) == ck["global_step"] for st in opt["state"].values()) and 0 not in opt["state"]  # index 0 = encoder.mask_token: no grad
+    assert ck["hyper_parameters"]["training_cfg"]["batch_size"] == 32 and ck["lr_schedulers"][0]["last_epoch"] == 1
+    assert ck["best_val_loss"] <= ck["val_loss"]
     raw = torch.load(out / "vit-mae.pt", weights_only=True)
     assert list(raw) == list(O.param_shapes(O.YAML_TINY))  # raw state_dict, reference key names
     lines = (out / "logs" / "metrics.jsonl").read_text().strip().splitlines()
@@ -261,6 +267,9 @@ def test_pretrain_cli_synthetic_run_and_resume(dev, tmp_path, monkeypatch):
               "--resume_from", str(out / "checkpoints" / "last.ckpt")])
     ck2 = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
     assert ck2["epoch"] == 2 and ck2["global_step"] > ck["global_step"]
+    assert ck2["best_val_loss"] <= ck["best_val_loss"]  # the best validation loss survives the resume
+    recs = [json.loads(x) for x in (out / "logs" / "metrics.jsonl").read_text().strip().splitlines()]
+    assert len(recs) == 3 and 0.0 < recs[2]["train_loss"] < 2 * recs[0]["train_loss"]  # per-epoch mean, not divided by all steps since the start
 
 
 def test_side_stream_wgrad_is_bitwise_identical(dev, monkeypatch):
