@@ -121,10 +121,32 @@ int mae_mse_loss(const float* pred, const float* target, int64_t n, float grad_s
 /* Backward of forward_decoder(forward_encoder(.)) given d_pred (batch, num_mask, P) fp32.
  * Writes (not accumulates) every trainable gradient into grads[0 .. trainable_elems).
  * Requires the workspace of the matching forward calls.  d_x_encoded_extra: optional extra
- * gradient (batch, num_keep, D) added at the encoder output (NULL on the MAE path). */
+ * gradient (batch, num_keep, D) fp32 added at the encoder output (NULL on the MAE path): a second consumer of
+ * x_encoded, e.g. a probe head trained next to the reconstruction loss. */
 int mae_engine_backward(mae_engine_t* e, const float* params, const void* wcache, const float* d_pred,
                         const float* d_x_encoded_extra, int32_t batch, int32_t num_keep, int32_t num_mask,
                         void* workspace, int64_t workspace_bytes, float* grads, void* stream);
+
+/* The two halves of mae_engine_backward, for callers that hold forward_encoder and forward_decoder as separate autograd
+ * nodes (the reference's fine-tuning hands encoder.vit to a classifier: scripts/training/train_mae.py:143,
+ * src/models/classifier.py:47-57).
+ * _decoder: d_pred -> every decoder gradient (arena range [mae_engine_encoder_grad_elems, trainable_elems)) and, when
+ *           d_x_encoded is not NULL, the gradient w.r.t. forward_decoder's x_encoded input (batch, num_keep, D) fp32.
+ * _encoder: d_x_encoded (batch, num_keep, D) fp32 -> every encoder gradient (arena range [0, encoder_grad_elems)).
+ * Each writes only its own range of `grads` and needs the workspace of the matching forward call. */
+int64_t mae_engine_encoder_grad_elems(const mae_engine_t* e);
+int mae_engine_backward_decoder(mae_engine_t* e, const float* params, const void* wcache, const float* d_pred,
+                                int32_t batch, int32_t num_keep, int32_t num_mask, void* workspace,
+                                int64_t workspace_bytes, float* grads, float* d_x_encoded, void* stream);
+int mae_engine_backward_encoder(mae_engine_t* e, const float* params, const void* wcache, const float* d_x_encoded,
+                                int32_t batch, int32_t num_keep, void* workspace, int64_t workspace_bytes,
+                                float* grads, void* stream);
+
+/* decoder.decode(x) (lightly MAEDecoderTIMM, called at src/models/mae.py:71): x (batch, L, Dd) fp32 ->
+ * decoder_norm(blocks(x + decoder_pos_embed)) for EVERY row, (batch, L, Dd) fp32.  Inference only (saves nothing).
+ * decoder.embed / decoder.predict (src/models/mae.py:59,73) are plain Linears: mae_linear_fwd. */
+int mae_engine_decoder_decode(mae_engine_t* e, const float* params, const void* wcache, const float* x, int32_t batch,
+                              void* workspace, int64_t workspace_bytes, float* out, void* stream);
 
 /* One fused pass: zero_grad + mask + forward + MSE + backward (training_step + loss.backward(),
  * src/training/mae.py:45-50).  noise (batch, L) fp32.  loss_out[0] = batch-mean MSE.

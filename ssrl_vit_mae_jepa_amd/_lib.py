@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
@@ -64,6 +65,10 @@ SIGNATURES = {
     "mae_mse_loss": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp]),
     "mae_engine_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mae_engine_loss_and_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mae_engine_encoder_grad_elems": (_i64, [_vp]),
+    "mae_engine_backward_decoder": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
+    "mae_engine_backward_encoder": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "mae_engine_decoder_decode": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     "mae_engine_grad_ready_points": (_i32, [_vp, _pp(_i64), _i32]),
     "mae_engine_loss_and_grads_phased": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _pp(_vp), _i32, _vp]),
     "mae_engine_optimizer_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _vp, _vp]),
@@ -94,8 +99,35 @@ if lib.mae_abi_version() != ABI_VERSION:  # pragma: no cover
     raise ImportError(f"libmae_hip.so ABI {lib.mae_abi_version()} != binding {ABI_VERSION}; rebuild the extension")
 
 
+# Tensors whose addresses were handed to the library by ptr() stay referenced here until the call has returned (check()
+# runs right after it): a temporary created inline in the call expression, e.g. ptr(x.float()), would otherwise be
+# freed -- and its block possibly re-issued by the caching allocator for the next argument -- before the launch.
+# Holding it until the launch is ENQUEUED is enough: the allocator reuses blocks in stream order.
+_alive = threading.local()
+
+
+def ptr(t, dtype=None) -> C.c_void_p:
+    """Device address of a contiguous CUDA tensor (None -> NULL); the tensor is kept alive until the next check()."""
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("libmae_hip works on device tensors only (no CPU fallback); move the tensor to cuda")
+    if not t.is_contiguous():
+        raise RuntimeError("libmae_hip needs contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    keep = getattr(_alive, "tensors", None)
+    if keep is None:
+        keep = _alive.tensors = []
+    keep.append(t)
+    return C.c_void_p(t.data_ptr())
+
+
 def check(rc: int) -> None:
     """Raise with the library's own message when a call returned non-zero."""
+    keep = getattr(_alive, "tensors", None)
+    if keep:
+        keep.clear()
     if rc != 0:
         msg = lib.mae_last_error()
         raise MaeHipError(msg.decode("utf-8", "replace") if msg else f"libmae_hip error {rc}")

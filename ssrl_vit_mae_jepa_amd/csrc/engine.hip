@@ -447,14 +447,25 @@ static int reach_point(const Ctx& c, int j) {
   return 0;
 }
 
-// dpred (act dtype) must already sit in the workspace
-static int backward_impl(const Ctx& c, const Plan& pl) {
-  mae_engine* e = c.e; hipStream_t s = c.s;
+static void backward_begin(const Ctx& c) {
+  mae_engine* e = c.e;
   e->ev_used = 0;
   for (auto& p : e->pending) p = nullptr;
+  e->ln_tab.n = 0;
+}
+static int backward_end(const Ctx& c) {
+  mae_engine* e = c.e; hipStream_t s = c.s;
+  if (e->ln_tab.n > 0) RUN(TK_LN_BWD, 0, 0, launch_sum_partials_many(e->ln_tab, s));  // dgamma / dbeta of every LayerNorm not yet retired: one launch
+  e->ln_tab.n = 0;
+  return join_side(c);
+}
+
+// Decoder half: dpred (act dtype) must already sit in the workspace; leaves d(x_encoded) (act dtype) in pl.d_ln and
+// every decoder gradient in its arena range [offset(decoder.mask_token), trainable_elems).
+static int backward_decoder_impl(const Ctx& c, const Plan& pl) {
+  mae_engine* e = c.e; hipStream_t s = c.s;
   float* dres = c.buf<float>(pl.dres);
   void* dres_c = c.buf<>(pl.dres_c);
-  e->ln_tab.n = 0;
   // prediction head
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.dpred), c.buf<>(pl.dec_norm), pl.Mp, e->P, e->Dd, e->i_pred_w, e->i_pred_b, DEP_MISC));
   MAE_TRY(dgrad(c, c.buf<>(pl.dpred), e->i_pred_w, pl.Mp, e->P, e->Dd, MAE_EPI_NONE, c.buf<>(pl.d_decn), nullptr));
@@ -469,8 +480,14 @@ static int backward_impl(const Ctx& c, const Plan& pl) {
   // decoder_embed
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_xdec), c.buf<>(pl.enc_norm), pl.Me, e->Dd, e->D, e->i_de_w, e->i_de_b, DEP_MISC));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_xdec), e->i_de_w, pl.Me, e->Dd, e->D, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
-  MAE_TRY(reach_point(c, 0));
-  // encoder final norm
+  return reach_point(c, 0);
+}
+
+// Encoder half: d(x_encoded) (act dtype) sits in pl.d_ln; writes the arena range [0, offset(decoder.mask_token)).
+static int backward_encoder_impl(const Ctx& c, const Plan& pl) {
+  mae_engine* e = c.e; hipStream_t s = c.s;
+  float* dres = c.buf<float>(pl.dres);
+  void* dres_c = c.buf<>(pl.dres_c);
   MAE_TRY(await_side(e, DEP_DRESC, s));
   RUN(TK_LN_BWD, 0, pl.Me * e->D * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(pl.enc_x[e->depth]), nullptr, c.P(e->i_norm_w), c.buf<float>(pl.enc_mean), c.buf<float>(pl.enc_rstd), pl.Me, e->D, 0, dres, dres_c, c.Gp(e->i_norm_w), c.Gp(e->i_norm_b), ln_slot(c, pl), s, &e->ln_tab));
   for (int i = e->depth - 1; i >= 0; --i) {
@@ -480,9 +497,16 @@ static int backward_impl(const Ctx& c, const Plan& pl) {
   // token assembly and patch projection
   RUN(TK_DATA, 0, pl.Me * e->D * (4 + c.as), launch_visible_grad_split(dres, c.buf<int32_t>(pl.keep32), pl.Me, e->D, c.act, c.buf<>(pl.dtok), c.Gp(e->i_cls), c.buf<float>(pl.split_partial), s));
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.dtok), c.buf<>(pl.patchA), pl.Me, e->D, e->P, e->i_patch_w, e->i_patch_b, DEP_MISC));
-  if (e->ln_tab.n > 0) RUN(TK_LN_BWD, 0, 0, launch_sum_partials_many(e->ln_tab, s));  // dgamma / dbeta of every LayerNorm not yet retired: one launch
-  e->ln_tab.n = 0;
-  MAE_TRY(join_side(c));
+  return 0;
+}
+
+static int backward_impl(const Ctx& c, const Plan& pl, const float* d_x_encoded_extra = nullptr) {
+  mae_engine* e = c.e; hipStream_t s = c.s;
+  backward_begin(c);
+  MAE_TRY(backward_decoder_impl(c, pl));
+  if (d_x_encoded_extra) MAE_TRY(launch_add_into(d_x_encoded_extra, c.buf<>(pl.d_ln), c.act, pl.Me * e->D, s));
+  MAE_TRY(backward_encoder_impl(c, pl));
+  MAE_TRY(backward_end(c));
   if (c.ready && c.ready[e->depth]) MAE_HIP(hipEventRecord((hipEvent_t)c.ready[e->depth], s));
   return 0;
 }
@@ -507,6 +531,9 @@ extern "C" int mae_engine_create(const mae_config_t* cfg, mae_engine_t** out) {
   MAE_REQUIRE(cfg->embed_dim % 4 == 0 && cfg->decoder_embed_dim % 4 == 0 && cfg->embed_dim <= 1024 && cfg->decoder_embed_dim <= 1024,
               "embed dims must be multiples of 4 and <= 1024");
   MAE_REQUIRE(cfg->act_dtype == MAE_F32 || cfg->act_dtype == MAE_BF16, "act_dtype must be MAE_F32 or MAE_BF16");
+  for (int hd : {cfg->embed_dim / cfg->num_heads, cfg->decoder_embed_dim / cfg->decoder_num_heads})
+    MAE_REQUIRE(hd == 16 || hd == 24 || hd == 32 || hd == 48 || hd == 64,
+                "head dim %d is not supported by the attention kernels (16, 24, 32, 48 or 64): choose num_heads accordingly", hd);
   const int P = cfg->patch_size * cfg->patch_size * cfg->in_chans;
   MAE_REQUIRE(P % 4 == 0, "patch_size^2 * in_chans must be a multiple of 4");
   mae_engine* e = new mae_engine();
@@ -652,12 +679,60 @@ extern "C" int mae_engine_backward(mae_engine_t* e, const float* params, const v
   Plan pl;
   MAE_TRY(check_call(e, params, wcache, batch, num_keep, workspace, workspace_bytes, &pl, "mae_engine_backward"));
   MAE_REQUIRE(d_pred && grads, "mae_engine_backward: null d_pred/grads");
-  MAE_REQUIRE(!d_x_encoded_extra, "mae_engine_backward: an extra gradient at x_encoded is not supported");
   MAE_REQUIRE(num_mask == pl.m && pl.m > 0, "mae_engine_backward: num_mask mismatch");
   hipStream_t s = (hipStream_t)stream;
   Ctx c{e, params, (const char*)wcache, grads, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
   MAE_TRY(launch_cast(d_pred, MAE_F32, c.buf<>(pl.dpred), e->act, pl.Mp * e->P, s));
-  return backward_impl(c, pl);
+  return backward_impl(c, pl, d_x_encoded_extra);
+}
+
+extern "C" int mae_engine_backward_decoder(mae_engine_t* e, const float* params, const void* wcache, const float* d_pred,
+                                           int32_t batch, int32_t num_keep, int32_t num_mask, void* workspace,
+                                           int64_t workspace_bytes, float* grads, float* d_x_encoded, void* stream) {
+  Plan pl;
+  MAE_TRY(check_call(e, params, wcache, batch, num_keep, workspace, workspace_bytes, &pl, "mae_engine_backward_decoder"));
+  MAE_REQUIRE(d_pred && grads, "mae_engine_backward_decoder: null d_pred/grads");
+  MAE_REQUIRE(num_mask == pl.m && pl.m > 0, "mae_engine_backward_decoder: num_mask mismatch");
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{e, params, (const char*)wcache, grads, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
+  MAE_TRY(launch_cast(d_pred, MAE_F32, c.buf<>(pl.dpred), e->act, pl.Mp * e->P, s));
+  backward_begin(c);
+  MAE_TRY(backward_decoder_impl(c, pl));
+  MAE_TRY(backward_end(c));
+  if (d_x_encoded) MAE_TRY(launch_cast(c.buf<>(pl.d_ln), e->act, d_x_encoded, MAE_F32, pl.Me * e->D, s));
+  return 0;
+}
+
+extern "C" int mae_engine_backward_encoder(mae_engine_t* e, const float* params, const void* wcache, const float* d_x_encoded,
+                                           int32_t batch, int32_t num_keep, void* workspace, int64_t workspace_bytes,
+                                           float* grads, void* stream) {
+  Plan pl;
+  MAE_TRY(check_call(e, params, wcache, batch, num_keep, workspace, workspace_bytes, &pl, "mae_engine_backward_encoder"));
+  MAE_REQUIRE(d_x_encoded && grads, "mae_engine_backward_encoder: null d_x_encoded/grads");
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{e, params, (const char*)wcache, grads, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
+  MAE_TRY(launch_cast(d_x_encoded, MAE_F32, c.buf<>(pl.d_ln), e->act, pl.Me * e->D, s));
+  backward_begin(c);
+  MAE_TRY(backward_encoder_impl(c, pl));
+  return backward_end(c);
+}
+
+extern "C" int64_t mae_engine_encoder_grad_elems(const mae_engine_t* e) { return e ? e->params[e->i_dec_mask].offset : 0; }
+
+// decoder.decode(x) of lightly MAEDecoderTIMM (src/models/mae.py:71): x + decoder_pos_embed -> blocks -> decoder_norm, every row
+extern "C" int mae_engine_decoder_decode(mae_engine_t* e, const float* params, const void* wcache, const float* x, int32_t batch,
+                                         void* workspace, int64_t workspace_bytes, float* out, void* stream) {
+  Plan pl;
+  MAE_TRY(check_call(e, params, wcache, batch, 1, workspace, workspace_bytes, &pl, "mae_engine_decoder_decode"));
+  MAE_REQUIRE(x && out, "mae_engine_decoder_decode: null x/out");
+  hipStream_t s = (hipStream_t)stream;
+  Ctx c{e, params, (const char*)wcache, nullptr, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
+  MAE_TRY(launch_add_rows_pos(x, c.P(e->i_dec_pos), pl.Md, e->L, e->Dd, c.buf<float>(pl.dec_x[0]), s));
+  for (int i = 0; i < e->dd; ++i)
+    MAE_TRY(block_forward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.B, e->L, i ? pl.dec[i - 1].x_mid : 0, i > 0, pl.dec_x[i]));
+  float* stat = c.buf<float>(pl.dres);  // scratch for the statistics of all B*L rows (dec_mean / dec_rstd hold the masked rows only)
+  return launch_layernorm_fwd(c.buf<float>(pl.dec[e->dd - 1].x_mid), c.buf<>(pl.branch_b), c.buf<float>(pl.dec_x[e->dd]), nullptr,
+                              c.P(e->i_dn_w), c.P(e->i_dn_b), 1e-6f, pl.Md, e->Dd, MAE_F32, out, stat, stat + pl.Md, s);
 }
 
 static int loss_and_grads_impl(mae_engine_t* e, const float* params, const void* wcache, const float* images, const float* noise,

@@ -346,6 +346,39 @@ int launch_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, h
   return 0;
 }
 
+// out[r] = x[r] + pos[r mod L]  (fp32, D/4 float4 per row): the `x + decoder_pos_embed` of decoder.decode()
+__global__ void add_rows_pos_kernel(const float* __restrict__ x, const float* __restrict__ pos, int64_t rows, int L, int D4,
+                                    float* __restrict__ out) {
+  const int64_t n = rows * D4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D4;
+    const int c = (int)(i - r * D4);
+    store4(out + i * 4, load4(x + i * 4) + load4(pos + ((r % L) * D4 + c) * 4));
+  }
+}
+int launch_add_rows_pos(const float* x, const float* pos, int64_t rows, int L, int D, float* out, hipStream_t s) {
+  MAE_REQUIRE(x && pos && out && rows > 0 && L > 0 && D % 4 == 0, "add_rows_pos: bad arguments");
+  const int grid = (int)std::min<int64_t>(cdiv(rows * (D / 4), 256), 256 * 16);
+  hipLaunchKernelGGL(add_rows_pos_kernel, dim3(grid), dim3(256), 0, s, x, pos, rows, L, D / 4, out);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// dst[i] (dt) += src[i] (fp32): an extra upstream gradient joins the engine's own one at a tensor boundary
+template <class T>
+__global__ void add_into_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = from_f<T>(to_f(dst[i]) + src[i]);
+}
+int launch_add_into(const float* src, void* dst, int dst_dt, int64_t n, hipStream_t s) {
+  MAE_REQUIRE(src && dst && n > 0, "add_into: bad arguments");
+  const int grid = (int)std::min<int64_t>(cdiv(n, 256), 256 * 16);
+  if (dst_dt == MAE_BF16) hipLaunchKernelGGL((add_into_kernel<bf16>), dim3(grid), dim3(256), 0, s, src, (bf16*)dst, n);
+  else hipLaunchKernelGGL((add_into_kernel<float>), dim3(grid), dim3(256), 0, s, src, (float*)dst, n);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace mae
 
 extern "C" int mae_patchify_gather(const float* images, const int64_t* idx_mask, int32_t batch, int32_t in_chans,

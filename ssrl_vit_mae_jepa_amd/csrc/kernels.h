@@ -36,6 +36,10 @@ int launch_decoder_assemble_bwd(const float* dx, const int32_t* inv, const int32
 int launch_patchify_gather(const float* images, const int32_t* mask32, int B, int m, int C, int img, int p,
                            float* target, hipStream_t s);
 int launch_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, hipStream_t s);
+// out[r] = x[r] + pos[r mod L] (fp32 rows of D)
+int launch_add_rows_pos(const float* x, const float* pos, int64_t rows, int L, int D, float* out, hipStream_t s);
+// dst (dt) += src (fp32)
+int launch_add_into(const float* src, void* dst, int dst_dt, int64_t n, hipStream_t s);
 // out[c] = sum_{i<G} partial[i][c] in row order (deterministic); columns [0,split) go to out0, [split,C) to out1
 int launch_sum_partials(const float* partial, int G, int C, float* out0, float* out1, int split, hipStream_t s);
 

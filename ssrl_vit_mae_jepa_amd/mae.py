@@ -23,16 +23,7 @@ def _stream(device: torch.device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _ptr(t: Optional[torch.Tensor], dtype: Optional[torch.dtype] = None) -> C.c_void_p:
-    if t is None:
-        return C.c_void_p(0)
-    if not t.is_cuda:
-        raise RuntimeError("libmae_hip works on device tensors only (no CPU fallback); move the tensor to cuda")
-    if not t.is_contiguous():
-        raise RuntimeError("libmae_hip needs contiguous tensors")
-    if dtype is not None and t.dtype != dtype:
-        raise TypeError(f"expected {dtype}, got {t.dtype}")
-    return C.c_void_p(t.data_ptr())
+_ptr = _lib.ptr  # keeps the tensor referenced until the call it is an argument of has returned
 
 
 class Engine:
@@ -92,20 +83,63 @@ class _Node(nn.Module):
 
 
 class _ViT(_Node):
+    """Stands where timm's VisionTransformer stands (``mae.encoder.vit``): ``blocks`` (indexable), ``norm``,
+    ``embed_dim``, ``forward_features`` -- what the reference's classifier touches (src/models/classifier.py:47-57,
+    src/training/classifier.py:144-165)."""
     embed_dim: int = 0
 
     def forward_features(self, images: torch.Tensor) -> torch.Tensor:
-        """timm VisionTransformer.forward_features: every token, no masking (scripts/training/train_mae.py:143)."""
+        """timm VisionTransformer.forward_features: every token, no masking (scripts/training/train_mae.py:143).
+        Differentiable w.r.t. the encoder parameters (one autograd node over the engine's encoder backward)."""
         return self._owner().forward_encoder(images, idx_keep=None)
+
+    def forward(self, images: torch.Tensor) -> torch.Tensor:
+        return self.forward_features(images)
 
 
 class _Encoder(_Node):
+    """lightly MaskedVisionTransformerTIMM surface used at src/models/mae.py:55."""
+
     def encode(self, images: torch.Tensor, idx_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self._owner().forward_encoder(images, idx_keep=idx_keep)
 
 
 class _Decoder(_Node):
-    pass
+    """lightly MAEDecoderTIMM surface used at src/models/mae.py:59-73: embed / decode / predict.  The three are
+    engine-backed inference calls; the differentiable route through the decoder is ``MaskedAutoencoder.forward_decoder``
+    (or ``forward``), so calling them where autograd would have to record raises instead of detaching silently."""
+
+    def _guard(self, what: str, x: torch.Tensor) -> "MaskedAutoencoder":
+        m = self._owner()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in m._dec_params)):
+            raise RuntimeError(f"decoder.{what}() is an inference call on the MI355X engine and records no autograd graph; "
+                               "use MaskedAutoencoder.forward_decoder()/forward() for gradients, or wrap the call in torch.no_grad()")
+        return m
+
+    def embed(self, x: torch.Tensor) -> torch.Tensor:
+        """decoder_embed Linear(D, Dd) (src/models/mae.py:59): (B, n, D) -> (B, n, Dd)."""
+        m = self._guard("embed", x)
+        return m._linear("decoder.decoder_embed", x, round_to_act=True)
+
+    def decode(self, x: torch.Tensor) -> torch.Tensor:
+        """+ decoder_pos_embed -> decoder blocks -> decoder_norm (src/models/mae.py:71): (B, L, Dd) -> (B, L, Dd)."""
+        m = self._guard("decode", x)
+        dev = m._require_cuda()
+        B, L, Dd = x.shape
+        if L != m.sequence_length or Dd != m._dims["decoder_embed_dim"]:
+            raise ValueError(f"decode expects (B, {m.sequence_length}, {m._dims['decoder_embed_dim']}), got {tuple(x.shape)}")
+        x = x.to(device=dev, dtype=torch.float32).contiguous()
+        ws = m._ws(B, 1)
+        m._gen_enc += 1; m._gen_dec += 1  # the block buffers of the workspace are overwritten
+        out = torch.empty_like(x)
+        check(lib.mae_engine_decoder_decode(m._engine.handle, _ptr(m._arena), _ptr(m._weights()), _ptr(x), B, _ptr(ws), ws.numel(),
+                                           _ptr(out), _stream(dev)))
+        return out
+
+    def predict(self, x: torch.Tensor) -> torch.Tensor:
+        """decoder_pred Linear(Dd, p*p*C) (src/models/mae.py:73): (B, n, Dd) -> (B, n, P)."""
+        m = self._guard("predict", x)
+        return m._linear("decoder.decoder_pred", x, round_to_act=False)
 
 
 class _MAEFunction(torch.autograd.Function):
@@ -115,7 +149,7 @@ class _MAEFunction(torch.autograd.Function):
     def forward(ctx, model: "MaskedAutoencoder", images, idx_keep, idx_mask, *params):
         x_pred, target = model._run_forward(images, idx_keep, idx_mask)
         ctx.model = model
-        ctx.generation = model._ws_generation
+        ctx.generation = (model._gen_enc, model._gen_dec)
         ctx.dims = (images.shape[0], idx_keep.shape[1], idx_mask.shape[1])
         ctx.mark_non_differentiable(target)
         return x_pred, target
@@ -123,11 +157,62 @@ class _MAEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_pred, _g_target):
         model = ctx.model
-        if ctx.generation != model._ws_generation:
-            raise RuntimeError("MaskedAutoencoder: another forward overwrote the saved activations before backward; "
-                               "run eval/validation forwards under torch.no_grad() or after backward")
+        if ctx.generation != (model._gen_enc, model._gen_dec):
+            raise RuntimeError(_STALE)
         grads = model._run_backward(g_pred.contiguous().float(), *ctx.dims)
         return (None, None, None, None, *grads)
+
+
+_STALE = ("MaskedAutoencoder: another forward overwrote the saved activations before backward; "
+          "run eval/validation forwards under torch.no_grad() or after backward")
+
+
+class _EncoderFunction(torch.autograd.Function):
+    """forward_encoder / forward_features as an autograd node: backward = mae_engine_backward_encoder."""
+
+    @staticmethod
+    def forward(ctx, model: "MaskedAutoencoder", images, idx_keep, *params):
+        out = model._run_encoder(images, idx_keep)
+        ctx.model, ctx.generation, ctx.dims = model, model._gen_enc, (images.shape[0], idx_keep.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        model = ctx.model
+        if ctx.generation != model._gen_enc:
+            raise RuntimeError(_STALE)
+        dev = model._require_cuda()
+        B, k = ctx.dims
+        ws = model._ws(B, k, keep=True)
+        buf = torch.zeros(model._engine.trainable_elems, dtype=torch.float32, device=dev)
+        check(lib.mae_engine_backward_encoder(model._engine.handle, _ptr(model._arena), _ptr(model._weights()), _ptr(g.contiguous().float()),
+                                             B, k, _ptr(ws), ws.numel(), _ptr(buf), _stream(dev)))
+        return (None, None, None, *model._views(buf, model._enc_table))
+
+
+class _DecoderFunction(torch.autograd.Function):
+    """forward_decoder as an autograd node: backward = mae_engine_backward_decoder (decoder gradients + d x_encoded)."""
+
+    @staticmethod
+    def forward(ctx, model: "MaskedAutoencoder", x_encoded, idx_keep, idx_mask, *params):
+        out = model._run_decoder(x_encoded, idx_keep, idx_mask)
+        ctx.model, ctx.generation = model, model._gen_dec
+        ctx.dims = (x_encoded.shape[0], idx_keep.shape[1], idx_mask.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        model = ctx.model
+        if ctx.generation != model._gen_dec:
+            raise RuntimeError(_STALE)
+        dev = model._require_cuda()
+        B, k, m = ctx.dims
+        ws = model._ws(B, k, keep=True)
+        buf = torch.zeros(model._engine.trainable_elems, dtype=torch.float32, device=dev)
+        dx = torch.empty(B, k, model._dims["embed_dim"], dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        check(lib.mae_engine_backward_decoder(model._engine.handle, _ptr(model._arena), _ptr(model._weights()), _ptr(g.contiguous().float()),
+                                             B, k, m, _ptr(ws), ws.numel(), _ptr(buf), _ptr(dx), _stream(dev)))
+        return (None, dx, None, None, *model._views(buf, model._dec_table))
 
 
 class MaskedAutoencoder(nn.Module):
@@ -159,7 +244,7 @@ class MaskedAutoencoder(nn.Module):
         self.encoder.vit = _ViT()
         self.encoder.vit.embed_dim = cfg["embed_dim"]
         owner = [self]  # no module cycle in nn.Module registration
-        for n in (self.encoder, self.encoder.vit):
+        for n in (self.encoder, self.encoder.vit, self.decoder):
             object.__setattr__(n, "_owner", lambda o=owner: o[0])
 
         self._arena = torch.zeros(self._engine.arena_elems, dtype=torch.float32)
@@ -172,12 +257,24 @@ class MaskedAutoencoder(nn.Module):
             if flags & _lib.PARAM_TRAINABLE:
                 self._trainable.append(p)
         self._init_weights()
+        # the two halves of the gradient arena (encoder tensors first): parameter lists of the per-half autograd nodes
+        split = lib.mae_engine_encoder_grad_elems(self._engine.handle)
+        rows = [(row, p) for row, (p, *_r) in zip(self._engine.table, self._slots) if row[4] & _lib.PARAM_TRAINABLE]
+        self._enc_table = [row for row, _p in rows if row[1] < split]
+        self._dec_table = [row for row, _p in rows if row[1] >= split]
+        self._enc_params = [p for row, p in rows if row[1] < split]
+        self._dec_params = [p for row, p in rows if row[1] >= split]
+        self._offsets = {row[0]: row for row in self._engine.table}
 
         self._grad_arena: Optional[torch.Tensor] = None
         self._wcache: Optional[torch.Tensor] = None
         self._wcache_version = -1
         self._workspace: Optional[torch.Tensor] = None
-        self._ws_generation = 0
+        # saved-activation bookkeeping: a forward bumps the generation of what it overwrites; a backward whose node saw
+        # an older generation refuses to run on someone else's activations
+        self._gen_enc = 0
+        self._gen_dec = 0
+        self._plan: Optional[Tuple[int, int]] = None
         self._scratch: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ construction helpers
@@ -187,7 +284,8 @@ class MaskedAutoencoder(nn.Module):
         for part in parts[:-1]:
             child = node._modules.get(part)
             if child is None:
-                child = _Node()
+                # timm keeps the blocks in an nn.Sequential: len(), indexing and slicing are part of the surface
+                child = nn.ModuleList() if part in ("blocks", "decoder_blocks") else _Node()
                 node.add_module(part, child)
             node = child
         node.register_parameter(parts[-1], p)
@@ -282,12 +380,40 @@ class MaskedAutoencoder(nn.Module):
                 self._wcache_version = v
         return self._wcache
 
-    def _ws(self, batch: int, num_keep: int) -> torch.Tensor:
+    def _ws(self, batch: int, num_keep: int, keep: bool = False) -> torch.Tensor:
+        """The workspace for (batch, num_keep).  Its layout is a function of that pair, so a forward with another pair
+        (or a reallocation) invalidates every saved activation; ``keep`` = a backward asking for its own forward's plan."""
         need = self._engine.workspace_bytes(batch, num_keep)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != self._arena.device:
+        realloc = self._workspace is None or self._workspace.numel() < need or self._workspace.device != self._arena.device
+        if keep and (realloc or self._plan != (batch, num_keep)):
+            raise RuntimeError(_STALE)
+        if realloc:
             self._workspace = None  # release before growing
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self._arena.device)
+        if realloc or self._plan != (batch, num_keep):
+            self._gen_enc += 1; self._gen_dec += 1
+            self._plan = (batch, num_keep)
         return self._workspace
+
+    def _views(self, flat: torch.Tensor, table) -> List[torch.Tensor]:
+        return [flat[off:off + numel].view(shape) for (_name, off, numel, shape, _flags) in table]
+
+    def _linear(self, prefix: str, x: torch.Tensor, round_to_act: bool) -> torch.Tensor:
+        """One Linear of the model through mae_linear_fwd (the engine's GEMM, operands in the engine's precision)."""
+        dev = self._require_cuda()
+        _n, w_off, w_numel, w_shape, _f = self._offsets[prefix + ".weight"]
+        _n, b_off, b_numel, _s, _f = self._offsets[prefix + ".bias"]
+        N, K = w_shape[0], w_numel // w_shape[0]
+        if x.shape[-1] != K:
+            raise ValueError(f"{prefix}: expected last dim {K}, got {tuple(x.shape)}")
+        bf = self._engine.act == _lib.MAE_BF16
+        a = x.to(device=dev, dtype=torch.bfloat16 if bf else torch.float32).contiguous().view(-1, K)
+        w = self._weights()[2 * w_off:2 * (w_off + w_numel)] if bf else self._arena[w_off:w_off + w_numel]
+        out_dt = self._engine.act if round_to_act else _lib.MAE_F32
+        out = torch.empty(a.shape[0], N, dtype=torch.bfloat16 if (bf and round_to_act) else torch.float32, device=dev)
+        check(lib.mae_linear_fwd(_ptr(a), _ptr(w), _ptr(self._arena[b_off:b_off + b_numel]), a.shape[0], N, K, self._engine.act,
+                                _lib.EPI_NONE, out_dt, _ptr(out), None, None, _stream(dev)))
+        return out.float().view(*x.shape[:-1], N)
 
     def _scratch_f32(self) -> torch.Tensor:
         if self._scratch is None or self._scratch.device != self._arena.device:
@@ -327,26 +453,42 @@ class MaskedAutoencoder(nn.Module):
             raise IndexError(f"{what} out of range [0, {self.sequence_length})")
         return idx
 
-    @torch.no_grad()
+    def _run_encoder(self, images: torch.Tensor, idx_keep: torch.Tensor) -> torch.Tensor:
+        dev = self._require_cuda()
+        B, k = images.shape[0], idx_keep.shape[1]
+        ws = self._ws(B, k)
+        self._gen_enc += 1; self._gen_dec += 1  # enc_norm, which the decoder's backward reads, is rewritten too
+        out = torch.empty(B, k, self._dims["embed_dim"], dtype=torch.float32, device=dev)
+        check(lib.mae_engine_forward_encoder(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images),
+                                            _ptr(idx_keep), B, k, _ptr(ws), ws.numel(), _ptr(out), _stream(dev)))
+        return out
+
     def forward_encoder(self, images: torch.Tensor, idx_keep: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """src/models/mae.py:54-55.  Not differentiable on its own (use forward())."""
+        """src/models/mae.py:54-55 -> (B, k, D).  Differentiable w.r.t. the encoder parameters: with grad enabled the
+        call is one autograd node whose backward is the engine's encoder backward (the classifier hand-off,
+        scripts/training/train_mae.py:143)."""
         dev = self._require_cuda()
         images = self._check_images(images)
         B = images.shape[0]
         if idx_keep is None:
             idx_keep = torch.arange(self.sequence_length, device=dev).repeat(B, 1)
         idx_keep = self._check_idx(idx_keep.to(dev), B, "idx_keep")
-        k = idx_keep.shape[1]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._enc_params):
+            return _EncoderFunction.apply(self, images, idx_keep, *self._enc_params)
+        return self._run_encoder(images, idx_keep)
+
+    def _run_decoder(self, x_encoded: torch.Tensor, idx_keep: torch.Tensor, idx_mask: torch.Tensor) -> torch.Tensor:
+        dev = self._require_cuda()
+        B, k, m = x_encoded.shape[0], idx_keep.shape[1], idx_mask.shape[1]
         ws = self._ws(B, k)
-        self._ws_generation += 1
-        out = torch.empty(B, k, self._dims["embed_dim"], dtype=torch.float32, device=dev)
-        check(lib.mae_engine_forward_encoder(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images),
-                                            _ptr(idx_keep), B, k, _ptr(ws), ws.numel(), _ptr(out), _stream(dev)))
+        self._gen_dec += 1
+        out = torch.empty(B, m, self.patch_dim, dtype=torch.float32, device=dev)
+        check(lib.mae_engine_forward_decoder(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(x_encoded),
+                                            _ptr(idx_keep), _ptr(idx_mask), B, k, m, _ptr(ws), ws.numel(), _ptr(out), _stream(dev)))
         return out
 
-    @torch.no_grad()
     def forward_decoder(self, x_encoded: torch.Tensor, idx_keep: torch.Tensor, idx_mask: torch.Tensor) -> torch.Tensor:
-        """src/models/mae.py:57-75.  Not differentiable on its own (use forward())."""
+        """src/models/mae.py:57-75 -> (B, m, p*p*C).  Differentiable w.r.t. x_encoded and the decoder parameters."""
         dev = self._require_cuda()
         B = x_encoded.shape[0]
         idx_keep = self._check_idx(idx_keep.to(dev), B, "idx_keep")
@@ -357,12 +499,9 @@ class MaskedAutoencoder(nn.Module):
         if k + m != self.sequence_length:
             raise ValueError("idx_keep and idx_mask must partition the sequence")
         x_encoded = x_encoded.to(device=dev, dtype=torch.float32).contiguous()
-        ws = self._ws(B, k)
-        self._ws_generation += 1
-        out = torch.empty(B, m, self.patch_dim, dtype=torch.float32, device=dev)
-        check(lib.mae_engine_forward_decoder(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(x_encoded),
-                                            _ptr(idx_keep), _ptr(idx_mask), B, k, m, _ptr(ws), ws.numel(), _ptr(out), _stream(dev)))
-        return out
+        if torch.is_grad_enabled() and (x_encoded.requires_grad or any(p.requires_grad for p in self._dec_params)):
+            return _DecoderFunction.apply(self, x_encoded, idx_keep, idx_mask, *self._dec_params)
+        return self._run_decoder(x_encoded, idx_keep, idx_mask)
 
     def patchify_gather(self, images: torch.Tensor, idx_mask: torch.Tensor) -> torch.Tensor:
         """utils.patchify + get_at_index(clamp(idx_mask - 1, 0)) (src/models/mae.py:90-92)."""
@@ -377,7 +516,7 @@ class MaskedAutoencoder(nn.Module):
         dev = self._require_cuda()
         B, k, m = images.shape[0], idx_keep.shape[1], idx_mask.shape[1]
         ws = self._ws(B, k)
-        self._ws_generation += 1
+        self._gen_enc += 1; self._gen_dec += 1
         h, w = self._engine.handle, self._weights()
         x_pred = torch.empty(B, m, self.patch_dim, dtype=torch.float32, device=dev)
         check(lib.mae_engine_forward_encoder(h, _ptr(self._arena), _ptr(w), _ptr(images), _ptr(idx_keep), B, k, _ptr(ws), ws.numel(),
@@ -388,7 +527,7 @@ class MaskedAutoencoder(nn.Module):
 
     def _run_backward(self, d_pred: torch.Tensor, B: int, k: int, m: int) -> List[torch.Tensor]:
         dev = self._require_cuda()
-        ws = self._ws(B, k)
+        ws = self._ws(B, k, keep=True)
         g = torch.zeros(self._engine.trainable_elems, dtype=torch.float32, device=dev)
         check(lib.mae_engine_backward(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(d_pred), None, B, k, m,
                                      _ptr(ws), ws.numel(), _ptr(g), _stream(dev)))
@@ -430,7 +569,7 @@ class MaskedAutoencoder(nn.Module):
         if noise.shape != (B, L) or noise.dtype != torch.float32 or not noise.is_contiguous():
             raise ValueError(f"noise must be a contiguous fp32 ({B}, {L}) tensor")
         ws = self._ws(B, k)
-        self._ws_generation += 1
+        self._gen_enc += 1; self._gen_dec += 1
         loss = torch.empty(1, dtype=torch.float32, device=dev) if loss_out is None else loss_out
         keep = mask = None
         if return_indices:
