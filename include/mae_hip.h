@@ -18,7 +18,12 @@
  *     operands with fp32 accumulation on the MFMA units (throughput).  The residual stream,
  *     LayerNorm statistics, losses, gradients of parameters and optimizer state are fp32
  *     in both modes;
- *   - token indices are int64 on the API (as torch.argsort returns them) and int32 inside.
+ *   - token indices are int64 on the API (as torch.argsort returns them) and int32 inside;
+ *   - images are (batch, C, H, W) NCHW, either MAE_F32 (already normalised, what the reference's
+ *     DataLoader yields after ToTensor + Normalize(.5,.5), src/data.py:15-24) or MAE_U8 (raw pixels
+ *     as the STL-10 file stores them): with MAE_U8 the kernels that read pixels apply
+ *     (u8/255 - 0.5)/0.5 themselves, bit-identical to the torch expression, and fetch every
+ *     image byte once per kernel.
  */
 #ifndef MAE_HIP_H
 #define MAE_HIP_H
@@ -30,9 +35,9 @@
 extern "C" {
 #endif
 
-#define MAE_ABI_VERSION 1
+#define MAE_ABI_VERSION 2
 
-enum { MAE_F32 = 0, MAE_BF16 = 1 };
+enum { MAE_F32 = 0, MAE_BF16 = 1, MAE_U8 = 2 /* images only */ };
 
 /* parameter flags (mae_engine_param_info) */
 enum {
@@ -93,11 +98,11 @@ int mae_mask_from_noise(const float* noise, int32_t batch, int32_t seq_len, int3
                         int64_t* idx_keep, int64_t* idx_mask, void* stream);
 
 /* MaskedAutoencoder.forward_encoder(images, idx_keep) (src/models/mae.py:54-55).
- * images (batch, C, H, W) fp32 NCHW; idx_keep (batch, num_keep) int64 token ids in [0, L);
+ * images (batch, C, H, W) NCHW in image_dtype (MAE_F32 | MAE_U8); idx_keep (batch, num_keep) int64 token ids in [0, L);
  * x_encoded (batch, num_keep, D) fp32.  Saves what backward needs in `workspace`. */
-int mae_engine_forward_encoder(mae_engine_t* e, const float* params, const void* wcache, const float* images,
-                               const int64_t* idx_keep, int32_t batch, int32_t num_keep, void* workspace,
-                               int64_t workspace_bytes, float* x_encoded, void* stream);
+int mae_engine_forward_encoder(mae_engine_t* e, const float* params, const void* wcache, const void* images,
+                               int32_t image_dtype, const int64_t* idx_keep, int32_t batch, int32_t num_keep,
+                               void* workspace, int64_t workspace_bytes, float* x_encoded, void* stream);
 
 /* MaskedAutoencoder.forward_decoder(x_encoded, idx_keep, idx_mask) (src/models/mae.py:57-75).
  * x_encoded may be NULL = "use the encoder output already in workspace" (the fused forward).
@@ -109,8 +114,9 @@ int mae_engine_forward_decoder(mae_engine_t* e, const float* params, const void*
 
 /* lightly utils.patchify + get_at_index(idx_mask-1) (src/models/mae.py:90-92):
  * target (batch, num_mask, p*p*C) fp32, per-patch order (py, px, c). */
-int mae_patchify_gather(const float* images, const int64_t* idx_mask, int32_t batch, int32_t in_chans,
-                        int32_t image_size, int32_t patch_size, int32_t num_mask, float* target, void* stream);
+int mae_patchify_gather(const void* images, int32_t image_dtype, const int64_t* idx_mask, int32_t batch,
+                        int32_t in_chans, int32_t image_size, int32_t patch_size, int32_t num_mask, float* target,
+                        void* stream);
 
 /* torch.nn.MSELoss() (src/training/mae.py:40,48) over n elements, and its gradient w.r.t. pred
  * scaled by grad_scale: loss[0] = mean((pred-target)^2); d_pred = grad_scale*2*(pred-target)/n.
@@ -152,8 +158,8 @@ int mae_engine_decoder_decode(mae_engine_t* e, const float* params, const void* 
  * src/training/mae.py:45-50).  noise (batch, L) fp32.  loss_out[0] = batch-mean MSE.
  * grad_scale multiplies the loss gradient (1/world_size for data-parallel sum-all-reduce).
  * idx_keep_out/idx_mask_out: optional int64 outputs (may be NULL). */
-int mae_engine_loss_and_grads(mae_engine_t* e, const float* params, const void* wcache, const float* images,
-                              const float* noise, int32_t batch, int32_t num_keep, float grad_scale,
+int mae_engine_loss_and_grads(mae_engine_t* e, const float* params, const void* wcache, const void* images,
+                              int32_t image_dtype, const float* noise, int32_t batch, int32_t num_keep, float grad_scale,
                               void* workspace, int64_t workspace_bytes, float* grads, float* loss_out,
                               int64_t* idx_keep_out, int64_t* idx_mask_out, void* stream);
 
@@ -167,8 +173,8 @@ int32_t mae_engine_grad_ready_points(const mae_engine_t* e, int64_t* offsets, in
  * `stream` when point j is reached, so that the caller can start the all-reduce of that arena range on another stream
  * while the rest of the backward pass still runs.  num_ready must equal mae_engine_grad_ready_points(). Results are
  * bit-identical to mae_engine_loss_and_grads. */
-int mae_engine_loss_and_grads_phased(mae_engine_t* e, const float* params, const void* wcache, const float* images,
-                                     const float* noise, int32_t batch, int32_t num_keep, float grad_scale,
+int mae_engine_loss_and_grads_phased(mae_engine_t* e, const float* params, const void* wcache, const void* images,
+                                     int32_t image_dtype, const float* noise, int32_t batch, int32_t num_keep, float grad_scale,
                                      void* workspace, int64_t workspace_bytes, float* grads, float* loss_out,
                                      int64_t* idx_keep_out, int64_t* idx_mask_out, void* const* ready_events,
                                      int32_t num_ready, void* stream);

@@ -14,10 +14,10 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("MAE_HIP_LIB") or _HERE / "lib" / "libmae_hip.so")  # MAE_HIP_LIB: an alternate build of the same library (kernel experiments)
 
-MAE_F32, MAE_BF16 = 0, 1
+MAE_F32, MAE_BF16, MAE_U8 = 0, 1, 2
 PARAM_TRAINABLE, PARAM_FROZEN, PARAM_UNUSED, PARAM_MATRIX = 1, 2, 4, 8
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL = 0, 1, 2, 3, 4, 5
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class MaeConfig(C.Structure):
@@ -59,18 +59,18 @@ SIGNATURES = {
     "mae_engine_wcache_bytes": (_i64, [_vp]),
     "mae_engine_refresh_weights": (C.c_int, [_vp, _vp, _vp, _vp]),
     "mae_mask_from_noise": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "mae_engine_forward_encoder": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
+    "mae_engine_forward_encoder": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mae_engine_forward_decoder": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
-    "mae_patchify_gather": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mae_patchify_gather": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "mae_mse_loss": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp]),
     "mae_engine_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
-    "mae_engine_loss_and_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mae_engine_loss_and_grads": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mae_engine_encoder_grad_elems": (_i64, [_vp]),
     "mae_engine_backward_decoder": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp]),
     "mae_engine_backward_encoder": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mae_engine_decoder_decode": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _vp]),
     "mae_engine_grad_ready_points": (_i32, [_vp, _pp(_i64), _i32]),
-    "mae_engine_loss_and_grads_phased": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _pp(_vp), _i32, _vp]),
+    "mae_engine_loss_and_grads_phased": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _pp(_vp), _i32, _vp]),
     "mae_engine_optimizer_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _vp, _vp]),
     "mae_engine_timers_enable": (C.c_int, [_vp, _i32]),
     "mae_engine_timer_count": (_i32, [_vp]),

@@ -400,10 +400,18 @@ static int check_call(const mae_engine* e, const void* params, const void* wcach
   return 0;
 }
 
-static int forward_encoder_impl(const Ctx& c, const Plan& pl, const float* images, float* x_encoded_out) {
+static int check_image_dtype(int dt, const char* who) {
+  MAE_REQUIRE(dt == MAE_F32 || dt == MAE_U8, "%s: image_dtype must be MAE_F32 or MAE_U8 (got %d)", who, dt);
+  return 0;
+}
+
+static int forward_encoder_impl(const Ctx& c, const Plan& pl, const void* images, int img_dt, float* x_encoded_out) {
   mae_engine* e = c.e; hipStream_t s = c.s;
   const int32_t* keep32 = c.buf<int32_t>(pl.keep32);
-  RUN(TK_DATA, 0, pl.Me * e->P * (4 + c.as), launch_gather_patches(images, keep32, pl.B, pl.k, e->C, e->img, e->p, c.act, c.buf<>(pl.patchA), s));
+  if (img_dt == MAE_U8)  // whole image rows through LDS: every pixel byte is fetched once
+    RUN(TK_DATA, 0, (int64_t)pl.B * e->C * e->img * e->img + pl.Me * e->P * c.as, launch_gather_patches_u8((const uint8_t*)images, keep32, pl.B, pl.k, e->C, e->img, e->p, c.act, c.buf<>(pl.patchA), s));
+  else
+    RUN(TK_DATA, 0, pl.Me * e->P * (4 + c.as), launch_gather_patches((const float*)images, keep32, pl.B, pl.k, e->C, e->img, e->p, c.act, c.buf<>(pl.patchA), s));
   MAE_TRY(linear(c, c.buf<>(pl.patchA), e->i_patch_w, e->i_patch_b, pl.Me, e->D, e->P, MAE_EPI_NONE, MAE_F32, c.buf<>(pl.enc_x[0]), nullptr, nullptr));
   RUN(TK_DATA, 0, pl.Me * e->D * 12, launch_assemble_visible(c.buf<float>(pl.enc_x[0]), keep32, c.P(e->i_cls), c.P(e->i_pos), pl.Me, e->D, s));
   for (int i = 0; i < e->depth; ++i)
@@ -646,16 +654,17 @@ extern "C" int mae_engine_refresh_weights(mae_engine_t* e, const float* params, 
   return refresh_transposed(e, params, wcache, s);
 }
 
-extern "C" int mae_engine_forward_encoder(mae_engine_t* e, const float* params, const void* wcache, const float* images,
-                                          const int64_t* idx_keep, int32_t batch, int32_t num_keep, void* workspace,
-                                          int64_t workspace_bytes, float* x_encoded, void* stream) {
+extern "C" int mae_engine_forward_encoder(mae_engine_t* e, const float* params, const void* wcache, const void* images,
+                                          int32_t image_dtype, const int64_t* idx_keep, int32_t batch, int32_t num_keep,
+                                          void* workspace, int64_t workspace_bytes, float* x_encoded, void* stream) {
   Plan pl;
   MAE_TRY(check_call(e, params, wcache, batch, num_keep, workspace, workspace_bytes, &pl, "mae_engine_forward_encoder"));
   MAE_REQUIRE(images && idx_keep, "mae_engine_forward_encoder: null images/idx_keep");
+  MAE_TRY(check_image_dtype(image_dtype, "mae_engine_forward_encoder"));
   hipStream_t s = (hipStream_t)stream;
   Ctx c{e, params, (const char*)wcache, nullptr, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
   MAE_TRY(launch_idx_to_i32(idx_keep, c.buf<int32_t>(pl.keep32), pl.Me, s));
-  return forward_encoder_impl(c, pl, images, x_encoded);
+  return forward_encoder_impl(c, pl, images, image_dtype, x_encoded);
 }
 
 extern "C" int mae_engine_forward_decoder(mae_engine_t* e, const float* params, const void* wcache, const float* x_encoded,
@@ -730,18 +739,23 @@ extern "C" int mae_engine_decoder_decode(mae_engine_t* e, const float* params, c
   MAE_TRY(launch_add_rows_pos(x, c.P(e->i_dec_pos), pl.Md, e->L, e->Dd, c.buf<float>(pl.dec_x[0]), s));
   for (int i = 0; i < e->dd; ++i)
     MAE_TRY(block_forward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.B, e->L, i ? pl.dec[i - 1].x_mid : 0, i > 0, pl.dec_x[i]));
-  float* stat = c.buf<float>(pl.dres);  // scratch for the statistics of all B*L rows (dec_mean / dec_rstd hold the masked rows only)
-  return launch_layernorm_fwd(c.buf<float>(pl.dec[e->dd - 1].x_mid), c.buf<>(pl.branch_b), c.buf<float>(pl.dec_x[e->dd]), nullptr,
-                              c.P(e->i_dn_w), c.P(e->i_dn_b), 1e-6f, pl.Md, e->Dd, MAE_F32, out, stat, stat + pl.Md, s);
+  // the fused add + LayerNorm kernel reads the branch in its OUTPUT dtype: first pass in the activation dtype (forms the last
+  // residual sum in dec_x[dd]; its normalised output goes to scratch), second pass writes fp32 rows for the caller
+  float* stat = c.buf<float>(pl.dres);  // statistics of all B*L rows (dec_mean / dec_rstd hold the masked rows only)
+  MAE_TRY(launch_layernorm_fwd(c.buf<float>(pl.dec[e->dd - 1].x_mid), c.buf<>(pl.branch_b), c.buf<float>(pl.dec_x[e->dd]), nullptr,
+                               c.P(e->i_dn_w), c.P(e->i_dn_b), 1e-6f, pl.Md, e->Dd, c.act, c.buf<>(pl.d_ln), stat, stat + pl.Md, s));
+  return launch_layernorm_fwd(c.buf<float>(pl.dec_x[e->dd]), nullptr, nullptr, nullptr, c.P(e->i_dn_w), c.P(e->i_dn_b), 1e-6f, pl.Md,
+                              e->Dd, MAE_F32, out, stat, stat + pl.Md, s);
 }
 
-static int loss_and_grads_impl(mae_engine_t* e, const float* params, const void* wcache, const float* images, const float* noise,
-                               int32_t batch, int32_t num_keep, float grad_scale, void* workspace, int64_t workspace_bytes, float* grads,
+static int loss_and_grads_impl(mae_engine_t* e, const float* params, const void* wcache, const void* images, int32_t image_dtype,
+                               const float* noise, int32_t batch, int32_t num_keep, float grad_scale, void* workspace, int64_t workspace_bytes, float* grads,
                                float* loss_out, int64_t* idx_keep_out, int64_t* idx_mask_out, void* const* ready, void* stream,
                                const char* who) {
   Plan pl;
   MAE_TRY(check_call(e, params, wcache, batch, num_keep, workspace, workspace_bytes, &pl, who));
   MAE_REQUIRE(images && noise && grads && loss_out, "%s: null argument", who);
+  MAE_TRY(check_image_dtype(image_dtype, who));
   MAE_REQUIRE(pl.m > 0, "%s: nothing is masked", who);
   hipStream_t s = (hipStream_t)stream;
   Ctx c{e, params, (const char*)wcache, grads, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
@@ -750,18 +764,21 @@ static int loss_and_grads_impl(mae_engine_t* e, const float* params, const void*
     TimerScope ts(e, TK_DATA, 0, (double)pl.Md * 12, s);
     MAE_TRY(launch_mask_from_noise(noise, batch, e->L, num_keep, idx_keep_out, idx_mask_out, c.buf<int32_t>(pl.keep32), c.buf<int32_t>(pl.mask32), s));
   }
-  MAE_TRY(forward_encoder_impl(c, pl, images, nullptr));
+  MAE_TRY(forward_encoder_impl(c, pl, images, image_dtype, nullptr));
   MAE_TRY(forward_decoder_impl(c, pl, nullptr));
-  RUN(TK_LOSS, 0, pl.Mp * e->P * (8 + c.as), launch_mse_from_images(c.buf<float>(pl.pred), images, c.buf<int32_t>(pl.mask32), batch, pl.m, e->C, e->img, e->p, grad_scale, loss_out, c.buf<>(pl.dpred), e->act, c.buf<float>(pl.loss_scratch), s));
+  if (image_dtype == MAE_U8)
+    RUN(TK_LOSS, 0, pl.Mp * e->P * (4 + c.as) + (int64_t)batch * e->C * e->img * e->img, launch_mse_from_images_u8(c.buf<float>(pl.pred), (const uint8_t*)images, c.buf<int32_t>(pl.mask32), batch, pl.m, e->C, e->img, e->p, grad_scale, loss_out, c.buf<>(pl.dpred), e->act, c.buf<float>(pl.loss_scratch), s));
+  else
+    RUN(TK_LOSS, 0, pl.Mp * e->P * (8 + c.as), launch_mse_from_images(c.buf<float>(pl.pred), (const float*)images, c.buf<int32_t>(pl.mask32), batch, pl.m, e->C, e->img, e->p, grad_scale, loss_out, c.buf<>(pl.dpred), e->act, c.buf<float>(pl.loss_scratch), s));
   return backward_impl(c, pl);
 }
 
-extern "C" int mae_engine_loss_and_grads(mae_engine_t* e, const float* params, const void* wcache, const float* images,
-                                         const float* noise, int32_t batch, int32_t num_keep, float grad_scale, void* workspace,
+extern "C" int mae_engine_loss_and_grads(mae_engine_t* e, const float* params, const void* wcache, const void* images,
+                                         int32_t image_dtype, const float* noise, int32_t batch, int32_t num_keep, float grad_scale, void* workspace,
                                          int64_t workspace_bytes, float* grads, float* loss_out, int64_t* idx_keep_out,
                                          int64_t* idx_mask_out, void* stream) {
-  return loss_and_grads_impl(e, params, wcache, images, noise, batch, num_keep, grad_scale, workspace, workspace_bytes, grads, loss_out,
-                             idx_keep_out, idx_mask_out, nullptr, stream, "mae_engine_loss_and_grads");
+  return loss_and_grads_impl(e, params, wcache, images, image_dtype, noise, batch, num_keep, grad_scale, workspace, workspace_bytes, grads,
+                             loss_out, idx_keep_out, idx_mask_out, nullptr, stream, "mae_engine_loss_and_grads");
 }
 
 extern "C" int32_t mae_engine_grad_ready_points(const mae_engine_t* e, int64_t* offsets, int32_t max_points) {
@@ -777,15 +794,15 @@ extern "C" int32_t mae_engine_grad_ready_points(const mae_engine_t* e, int64_t* 
   return n;
 }
 
-extern "C" int mae_engine_loss_and_grads_phased(mae_engine_t* e, const float* params, const void* wcache, const float* images,
-                                                const float* noise, int32_t batch, int32_t num_keep, float grad_scale, void* workspace,
+extern "C" int mae_engine_loss_and_grads_phased(mae_engine_t* e, const float* params, const void* wcache, const void* images,
+                                                int32_t image_dtype, const float* noise, int32_t batch, int32_t num_keep, float grad_scale, void* workspace,
                                                 int64_t workspace_bytes, float* grads, float* loss_out, int64_t* idx_keep_out,
                                                 int64_t* idx_mask_out, void* const* ready_events, int32_t num_ready, void* stream) {
   MAE_REQUIRE(e, "mae_engine_loss_and_grads_phased: null engine");
   MAE_REQUIRE(ready_events && num_ready == e->depth + 1,
               "mae_engine_loss_and_grads_phased: need one event slot per gradient-ready point (%d), got %d", e->depth + 1, num_ready);
-  return loss_and_grads_impl(e, params, wcache, images, noise, batch, num_keep, grad_scale, workspace, workspace_bytes, grads, loss_out,
-                             idx_keep_out, idx_mask_out, ready_events, stream, "mae_engine_loss_and_grads_phased");
+  return loss_and_grads_impl(e, params, wcache, images, image_dtype, noise, batch, num_keep, grad_scale, workspace, workspace_bytes, grads,
+                             loss_out, idx_keep_out, idx_mask_out, ready_events, stream, "mae_engine_loss_and_grads_phased");
 }
 
 extern "C" int mae_engine_optimizer_step(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,

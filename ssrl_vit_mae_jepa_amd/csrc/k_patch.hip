@@ -381,9 +381,13 @@ int launch_add_into(const float* src, void* dst, int dst_dt, int64_t n, hipStrea
 
 }  // namespace mae
 
-extern "C" int mae_patchify_gather(const float* images, const int64_t* idx_mask, int32_t batch, int32_t in_chans,
+extern "C" int mae_patchify_gather(const void* images, int32_t image_dtype, const int64_t* idx_mask, int32_t batch, int32_t in_chans,
                                    int32_t image_size, int32_t patch_size, int32_t num_mask, float* target,
                                    void* stream) {
-  return mae::launch_patchify_gather_i64(images, idx_mask, batch, num_mask, in_chans, image_size, patch_size, target,
+  MAE_REQUIRE(image_dtype == MAE_F32 || image_dtype == MAE_U8, "mae_patchify_gather: image_dtype must be MAE_F32 or MAE_U8 (got %d)", image_dtype);
+  if (image_dtype == MAE_U8)
+    return mae::launch_patchify_gather_u8_i64((const uint8_t*)images, idx_mask, batch, num_mask, in_chans, image_size, patch_size, target,
+                                              (hipStream_t)stream);
+  return mae::launch_patchify_gather_i64((const float*)images, idx_mask, batch, num_mask, in_chans, image_size, patch_size, target,
                                          (hipStream_t)stream);
 }

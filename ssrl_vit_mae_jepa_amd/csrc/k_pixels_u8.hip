@@ -1,0 +1,244 @@
+// uint8 pixels read inside the engine: the three kernels that touch the image (visible-patch gather, masked-pixel MSE,
+// target patchify) with ToTensor + Normalize(.5, .5) fused into the read (reference: src/data.py:15-24 builds
+// transforms.ToTensor() -> x / 255, then Normalize(mean .5, std .5) -> (x - .5) / .5; here v = (u8 / 255 - 0.5) / 0.5 with
+// an IEEE-rounded division, bit-identical to the torch fp32 expression).
+//
+// Data movement: a patch row of a uint8 image is p bytes (8 for ViT-S/8), far below a 128-byte HBM line, so a gather by
+// patch would pull 16x the bytes it uses.  Instead one workgroup owns one BAND = one row of patches of one image
+// (C x p x W bytes: 2.3 KB at 96 px / p 8, 10.5 KB at 224 px / p 16), streams it into LDS with coalesced 4-byte loads,
+// then serves the band's visible (or masked) tokens from LDS.  Every image byte is fetched exactly once per kernel:
+// 27.6 KB per image instead of the 110.6 KB fp32 image read as scattered 32-byte patch rows (3.9x / 2.3x over-fetch
+// measured in round 1).  All HBM-bound, 55 MB per launch at batch 2000.
+#include "kernels.h"
+
+namespace mae {
+
+namespace {
+
+// The tokens of one band are listed in LDS behind the band image: n_tok slots, so that even an index list that names one
+// band over and over (legal for a caller-made idx_keep) is served completely.
+
+__device__ __forceinline__ float norm_u8(unsigned u) { return (__fdiv_rn((float)u, 255.0f) - 0.5f) / 0.5f; }
+
+// band (b, ph) -> LDS image [C][p][W] bytes (W % 4 == 0)
+__device__ __forceinline__ void load_band(const uint8_t* __restrict__ images, int64_t b, int ph, int C, int img, int p, unsigned* lds32) {
+  const int wpr = img >> 2, words = C * p * wpr;
+  for (int w = threadIdx.x; w < words; w += 256) {
+    const int row = w / wpr, col = w - row * wpr;
+    const int c = row / p, py = row - c * p;
+    const unsigned* src = reinterpret_cast<const unsigned*>(images + ((b * C + c) * (int64_t)img + (ph * p + py)) * img);
+    lds32[w] = src[col];
+  }
+}
+
+// tokens of image b that lie in band ph -> list (j index, patch column); class token (t == 0) belongs to band 0 when with_cls
+template <class I>
+__device__ __forceinline__ void band_tokens(const I* __restrict__ tok, int64_t b, int n_tok, int g, int ph, bool with_cls, int* list, int* cnt) {
+  for (int j = threadIdx.x; j < n_tok; j += 256) {
+    const int t = (int)tok[b * n_tok + j];
+    bool mine;
+    int pw;
+    if (t <= 0 && with_cls) { mine = ph == 0; pw = -1; }  // class token: a zero row
+    else {  // idx - 1 clamped into the patch grid (the reference's clamp(idx_mask - 1, min=0), src/models/mae.py:91)
+      const int n = t <= 0 ? 0 : (t - 1 < g * g ? t - 1 : g * g - 1); mine = n / g == ph; pw = n - (n / g) * g;
+    }
+    if (mine) {
+      const int slot = atomicAdd(cnt, 1);
+      list[slot] = (j << 8) | (pw & 0xff);
+    }
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// visible-patch gather: out[(b, j)][c*p*p + py*p + px] = normalised pixel, zero row for the class token
+// ---------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(256) gather_patches_u8_kernel(const uint8_t* __restrict__ images, const int32_t* __restrict__ tok, int B,
+                                                                int k, int C, int img, int p, T* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds32[];
+  int* list = reinterpret_cast<int*>(lds32 + C * p * (img >> 2));
+  __shared__ int cnt;
+  const int g = img / p, P = C * p * p, p4 = p >> 2, units = C * p * p4;
+  const uint8_t* band = reinterpret_cast<const uint8_t*>(lds32);
+  for (int64_t bb = blockIdx.x; bb < (int64_t)B * g; bb += gridDim.x) {
+    const int64_t b = bb / g;
+    const int ph = (int)(bb - b * g);
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    load_band(images, b, ph, C, img, p, lds32);
+    band_tokens(tok, b, k, g, ph, true, list, &cnt);
+    __syncthreads();
+    const int n = cnt;
+    for (int it = threadIdx.x; it < n * units; it += 256) {
+      const int li = it / units, u = it - li * units;
+      const int j = list[li] >> 8, pw = list[li] & 0xff;
+      const int c = u / (p * p4), rem = u - c * (p * p4);
+      const int py = rem / p4, px = (rem - py * p4) << 2;
+      T* dst = out + (b * k + j) * (int64_t)P + (c * p + py) * p + px;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pw != 0xff) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(band + (c * p + py) * img + pw * p + px);
+        v = f32x4{norm_u8(w & 0xff), norm_u8((w >> 8) & 0xff), norm_u8((w >> 16) & 0xff), norm_u8(w >> 24)};
+      }
+      store4(dst, v);
+    }
+    __syncthreads();
+  }
+}
+
+int launch_gather_patches_u8(const uint8_t* images, const int32_t* tok, int B, int k, int C, int img, int p, int dt, void* out,
+                             hipStream_t s) {
+  MAE_REQUIRE(images && tok && out && B > 0 && k > 0, "gather_patches(u8): bad arguments");
+  MAE_REQUIRE(p > 0 && img % p == 0 && p % 4 == 0 && img / p <= 64, "uint8 images need patch_size %% 4 == 0 and at most 64 patches per side (got image %d, patch %d)", img, p);
+  MAE_REQUIRE(C * p * img <= 96 * 1024 && k <= 8192, "uint8 images: one row of patches (%d bytes) does not fit the LDS band", C * p * img);
+  const int grid = (int)std::min<int64_t>((int64_t)B * (img / p), 256 * 16);
+  const size_t lds = (size_t)C * p * img + (size_t)k * 4;
+  if (dt == MAE_BF16) hipLaunchKernelGGL((gather_patches_u8_kernel<bf16>), dim3(grid), dim3(256), lds, s, images, tok, B, k, C, img, p, (bf16*)out);
+  else hipLaunchKernelGGL((gather_patches_u8_kernel<float>), dim3(grid), dim3(256), lds, s, images, tok, B, k, C, img, p, (float*)out);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// masked-pixel MSE against the image (target never materialised) + dpred; element order of a row: (py, px, c)
+// ---------------------------------------------------------------------------------------------------
+template <class T, bool HAS_GRAD>
+__global__ void __launch_bounds__(256) mse_images_u8_kernel(const float* __restrict__ pred, const uint8_t* __restrict__ images,
+                                                            const int32_t* __restrict__ mask32, int B, int m, int C, int img, int p,
+                                                            float gscale, float* __restrict__ partial, T* __restrict__ dpred) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds32[];
+  int* list = reinterpret_cast<int*>(lds32 + C * p * (img >> 2));
+  __shared__ int cnt;
+  __shared__ float red[4];
+  const int g = img / p, P = C * p * p, p4 = p >> 2, units = p * p4;
+  const uint8_t* band = reinterpret_cast<const uint8_t*>(lds32);
+  float acc = 0.f;
+  for (int64_t bb = blockIdx.x; bb < (int64_t)B * g; bb += gridDim.x) {
+    const int64_t b = bb / g;
+    const int ph = (int)(bb - b * g);
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    load_band(images, b, ph, C, img, p, lds32);
+    band_tokens(mask32, b, m, g, ph, false, list, &cnt);
+    __syncthreads();
+    const int n = cnt;
+    for (int it = threadIdx.x; it < n * units; it += 256) {
+      const int li = it / units, u = it - li * units;
+      const int j = list[li] >> 8, pw = list[li] & 0xff;
+      const int py = u / p4, px = (u - py * p4) << 2;
+      const int64_t o = (b * m + j) * (int64_t)P + (py * p + px) * C;  // 4 pixels x C channels = 4C contiguous elements
+      const uint8_t* src = band + py * img + pw * p + px;
+      for (int v = 0; v < C; ++v) {
+        const f32x4 pr = load4(pred + o + 4 * v);
+        f32x4 d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = 4 * v + i, pxi = e / C, c = e - pxi * C;
+          d[i] = pr[i] - norm_u8(src[c * p * img + pxi]);
+          acc += d[i] * d[i];
+        }
+        if (HAS_GRAD) store4(dpred + o + 4 * v, d * gscale);
+      }
+    }
+    __syncthreads();
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(256) mean_finalize_u8_kernel(const float* __restrict__ partial, int nb, float inv_n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = acc * inv_n;
+}
+
+int launch_mse_from_images_u8(const float* pred, const uint8_t* images, const int32_t* mask32, int B, int m, int C, int img, int p,
+                              float grad_scale, float* loss, void* d_pred, int dpred_dt, float* scratch, hipStream_t s) {
+  MAE_REQUIRE(pred && images && mask32 && loss && scratch && B > 0 && m > 0, "mse_from_images(u8): bad arguments");
+  MAE_REQUIRE(p > 0 && img % p == 0 && p % 4 == 0 && img / p <= 64 && C * p * img <= 96 * 1024 && m <= 8192, "uint8 images: unsupported geometry (image %d, patch %d)", img, p);
+  const int64_t n = (int64_t)B * m * p * p * C;
+  const int grid = (int)std::min<int64_t>((int64_t)B * (img / p), 1024);  // stage-1 partials: scratch holds 1024 floats + 8
+  const float gs = grad_scale * 2.0f / (float)n;
+  const size_t lds = (size_t)C * p * img + (size_t)m * 4;
+  if (!d_pred)
+    hipLaunchKernelGGL((mse_images_u8_kernel<float, false>), dim3(grid), dim3(256), lds, s, pred, images, mask32, B, m, C, img, p, gs, scratch, (float*)nullptr);
+  else if (dpred_dt == MAE_BF16)
+    hipLaunchKernelGGL((mse_images_u8_kernel<bf16, true>), dim3(grid), dim3(256), lds, s, pred, images, mask32, B, m, C, img, p, gs, scratch, (bf16*)d_pred);
+  else
+    hipLaunchKernelGGL((mse_images_u8_kernel<float, true>), dim3(grid), dim3(256), lds, s, pred, images, mask32, B, m, C, img, p, gs, scratch, (float*)d_pred);
+  MAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mean_finalize_u8_kernel, dim3(1), dim3(256), 0, s, scratch, grid, 1.0f / (float)n, loss);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// target (B*m, P) fp32 in (py, px, c) order for patch max(mask - 1, 0): utils.patchify + get_at_index on uint8 pixels
+// ---------------------------------------------------------------------------------------------------
+template <class I>
+__global__ void __launch_bounds__(256) patchify_gather_u8_kernel(const uint8_t* __restrict__ images, const I* __restrict__ mask, int B, int m,
+                                                                 int C, int img, int p, float* __restrict__ target) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds32[];
+  int* list = reinterpret_cast<int*>(lds32 + C * p * (img >> 2));
+  __shared__ int cnt;
+  const int g = img / p, P = C * p * p, p4 = p >> 2, units = p * p4;
+  const uint8_t* band = reinterpret_cast<const uint8_t*>(lds32);
+  for (int64_t bb = blockIdx.x; bb < (int64_t)B * g; bb += gridDim.x) {
+    const int64_t b = bb / g;
+    const int ph = (int)(bb - b * g);
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    load_band(images, b, ph, C, img, p, lds32);
+    // clamp(idx - 1, 0): a class-token id (0) reads patch 0, like the reference's clamp (it never occurs in idx_mask)
+    for (int j = threadIdx.x; j < m; j += 256) {
+      int n = (int)mask[b * m + j] - 1;
+      n = n < 0 ? 0 : (n >= g * g ? g * g - 1 : n);
+      if (n / g == ph) {
+        const int slot = atomicAdd(&cnt, 1);
+        list[slot] = (j << 8) | (n - (n / g) * g);
+      }
+    }
+    __syncthreads();
+    const int n = cnt;
+    for (int it = threadIdx.x; it < n * units; it += 256) {
+      const int li = it / units, u = it - li * units;
+      const int j = list[li] >> 8, pw = list[li] & 0xff;
+      const int py = u / p4, px = (u - py * p4) << 2;
+      const int64_t o = (b * m + j) * (int64_t)P + (py * p + px) * C;
+      const uint8_t* src = band + py * img + pw * p + px;
+      for (int v = 0; v < C; ++v) {
+        f32x4 d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = 4 * v + i, pxi = e / C, c = e - pxi * C;
+          d[i] = norm_u8(src[c * p * img + pxi]);
+        }
+        store4(target + o + 4 * v, d);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <class I>
+static int launch_patchify_u8(const uint8_t* images, const I* mask, int B, int m, int C, int img, int p, float* target, hipStream_t s) {
+  MAE_REQUIRE(images && mask && target && B > 0 && m > 0, "patchify_gather(u8): bad arguments");
+  MAE_REQUIRE(p > 0 && img % p == 0 && p % 4 == 0 && img / p <= 64 && C * p * img <= 96 * 1024, "uint8 images: unsupported geometry (image %d, patch %d)", img, p);
+  MAE_REQUIRE(m <= 8192, "patchify_gather(u8): too many tokens per image");
+  const int grid = (int)std::min<int64_t>((int64_t)B * (img / p), 256 * 16);
+  hipLaunchKernelGGL((patchify_gather_u8_kernel<I>), dim3(grid), dim3(256), (size_t)C * p * img + (size_t)m * 4, s, images, mask, B, m, C, img, p, target);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+int launch_patchify_gather_u8(const uint8_t* images, const int32_t* mask32, int B, int m, int C, int img, int p, float* target, hipStream_t s) {
+  return launch_patchify_u8(images, mask32, B, m, C, img, p, target, s);
+}
+int launch_patchify_gather_u8_i64(const uint8_t* images, const int64_t* mask64, int B, int m, int C, int img, int p, float* target, hipStream_t s) {
+  return launch_patchify_u8(images, mask64, B, m, C, img, p, target, s);
+}
+
+}  // namespace mae

@@ -35,6 +35,12 @@ int launch_decoder_assemble_bwd(const float* dx, const int32_t* inv, const int32
 // target (B*m, P) fp32 in (py, px, c) order for patch max(mask[b][j]-1, 0)
 int launch_patchify_gather(const float* images, const int32_t* mask32, int B, int m, int C, int img, int p,
                            float* target, hipStream_t s);
+// ---- k_pixels_u8.hip: the same three pixel readers on uint8 images, ToTensor + Normalize(.5,.5) fused into the read -----
+int launch_gather_patches_u8(const uint8_t* images, const int32_t* tok, int B, int k, int C, int img, int p, int dt, void* out, hipStream_t s);
+int launch_mse_from_images_u8(const float* pred, const uint8_t* images, const int32_t* mask32, int B, int m, int C, int img, int p,
+                              float grad_scale, float* loss, void* d_pred, int dpred_dt, float* scratch, hipStream_t s);
+int launch_patchify_gather_u8(const uint8_t* images, const int32_t* mask32, int B, int m, int C, int img, int p, float* target, hipStream_t s);
+int launch_patchify_gather_u8_i64(const uint8_t* images, const int64_t* mask64, int B, int m, int C, int img, int p, float* target, hipStream_t s);
 int launch_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, hipStream_t s);
 // out[r] = x[r] + pos[r mod L] (fp32 rows of D)
 int launch_add_rows_pos(const float* x, const float* pos, int64_t rows, int L, int D, float* out, hipStream_t s);

@@ -1,9 +1,14 @@
-"""Input step before the hot path: batches of (B, 3, 96, 96) fp32 images in [-1, 1], resident on the GPU.
+"""Input step before the hot path: batches of (B, 3, 96, 96) images, uint8 as the dataset stores them, on the GPU.
 
 Mirrors what the reference's ``get_pretrain_dataloaders`` (src/data.py:45-106) hands the step, without torchvision
-(not installed): the STL-10 unlabeled split is read straight from its binary file (uint8, column-major images), kept as
-uint8 on the device (27.6 KB/image instead of 110.6 KB fp32) and normalised with ToTensor + Normalize(.5,.5) arithmetic
-on the GPU; the 94 000 / 6 000 split uses ``random_split``'s permutation with generator seed 73 (src/data.py:74-80).
+(not installed): the STL-10 unlabeled split is read straight from its binary file (uint8, column-major images) and kept
+uint8 all the way INTO the engine (27.6 KB/image instead of 110.6 KB fp32): ToTensor + Normalize(.5,.5)
+(src/data.py:22-23) is applied by the kernels that read pixels (csrc/k_pixels_u8.hip), bit-identical to the torch
+expression ``normalize_u8``.  The dataset lives either on the device (``engine.data_on_device: true``, the default:
+2.6 GB for STL-10 unlabeled) or in pinned host memory, streamed by ``PinnedBatchStream``: index gather on the host into
+a pinned staging buffer, H2D copy on a side stream into one of two device buffers, so batch i+1 crosses PCIe while
+batch i trains (55 MB per 2000-image batch: 0.9 ms at 63 GB/s against a 25 ms step).
+The 94 000 / 6 000 split uses ``random_split``'s permutation with generator seed 73 (src/data.py:74-80).
 Augmentation follows what the reference actually does, quirk included (src/data.py:74-81): ``val_subset.dataset`` is the
 object ``random_split`` was given, so with data_fraction == 1.0 the assignment overwrites the shared STL10 transform and
 BOTH loaders serve un-augmented images, while with data_fraction < 1.0 it lands on the ``Subset`` wrapper, does nothing,
@@ -80,6 +85,58 @@ def augment_batch(x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
     return F.grid_sample(x, grid, mode="bilinear", padding_mode="border", align_corners=False)
 
 
+class PinnedBatchStream:
+    """uint8 dataset in pinned host memory -> device batches through two device buffers (double buffering).
+
+    ``batches(order)`` yields ``data[order[i:i+batch]]`` as device tensors.  While the consumer works on buffer s, the next
+    batch is gathered on the host into pinned staging buffer 1-s and copied on ``copy_stream``; the consumer's stream waits
+    for the copy's event (never the host), and a buffer is rewritten only after the kernels that read it have finished
+    (an event recorded on the consumer's stream when the next batch is requested)."""
+
+    def __init__(self, data_u8: torch.Tensor, batch: int, device: torch.device):
+        if data_u8.dtype != torch.uint8 or data_u8.is_cuda:
+            raise ValueError("PinnedBatchStream takes a uint8 host tensor")
+        self.device, self.batch = device, int(batch)
+        self.data = data_u8.contiguous()
+        shape = (self.batch,) + tuple(data_u8.shape[1:])
+        self.stage = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.dev = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+        self.staged = [torch.cuda.Event() for _ in range(2)]   # the H2D copy out of a staging buffer has finished
+        self._used = [False, False]
+
+    def _submit(self, slot: int, idx: torch.Tensor) -> int:
+        n = idx.numel()
+        if self._used[slot]:
+            self.staged[slot].synchronize()  # host: the previous copy out of this staging buffer is done
+        torch.index_select(self.data, 0, idx, out=self.stage[slot][:n])
+        with torch.cuda.stream(self.copy_stream):
+            if self._used[slot]:
+                self.copy_stream.wait_event(self.free[slot])  # device: the consumer finished with this buffer
+            self.dev[slot][:n].copy_(self.stage[slot][:n], non_blocking=True)
+            self.staged[slot].record(self.copy_stream)
+            self.ready[slot].record(self.copy_stream)
+        self._used[slot] = True
+        return n
+
+    def batches(self, order: torch.Tensor) -> Iterator[torch.Tensor]:
+        order = order.to("cpu", torch.int64)
+        chunks = [order[i:i + self.batch] for i in range(0, order.numel(), self.batch)]
+        if not chunks:
+            return
+        n_next = self._submit(0, chunks[0])
+        for i in range(len(chunks)):
+            slot, n = i & 1, n_next
+            if i + 1 < len(chunks):
+                n_next = self._submit(1 - slot, chunks[i + 1])  # overlaps whatever the consumer enqueued for batch i-1
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self.ready[slot])
+            yield self.dev[slot][:n]
+            self.free[slot].record(torch.cuda.current_stream(self.device))  # everything the consumer enqueued on it so far
+
+
 def get_pretrain_batches(cfg: dict, device: torch.device, synthetic_images: Optional[int] = None,
                          seed: int = 73) -> Tuple[Callable[[int], Iterator[torch.Tensor]], Callable[[], Iterator[torch.Tensor]]]:
     pre = cfg["pretrain"]
@@ -87,10 +144,17 @@ def get_pretrain_batches(cfg: dict, device: torch.device, synthetic_images: Opti
     val_split = float(pre.get("val_split", 0.1))
     fraction = float(pre.get("data_fraction", 1.0))
     seed = int(cfg.get("seed", seed))
+    on_device = bool(cfg.get("engine", {}).get("data_on_device", True))
+    stream: Optional[PinnedBatchStream] = None
     if synthetic_images is None and STL10_UNLABELED.exists():
-        data = _load_stl10_unlabeled(STL10_UNLABELED, fraction).to(device)  # uint8 on device
-        fetch = lambda idx: normalize_u8(data[idx])  # noqa: E731
-        n_total = data.shape[0]
+        host = _load_stl10_unlabeled(STL10_UNLABELED, fraction)
+        n_total = host.shape[0]
+        if on_device:
+            data = host.to(device)  # uint8 on device; the engine normalises while it reads
+            fetch = lambda idx: data[idx]  # noqa: E731
+        else:
+            stream = PinnedBatchStream(host.pin_memory(), batch, device)
+            fetch = None
     else:
         n_total = int(synthetic_images or 4 * batch)
         g = torch.Generator(device=device).manual_seed(seed)
@@ -99,21 +163,32 @@ def get_pretrain_batches(cfg: dict, device: torch.device, synthetic_images: Opti
     n_val = int(n_total * val_split)
     n_train = n_total - n_val
     perm = torch.randperm(n_total, generator=torch.Generator().manual_seed(seed))  # random_split's permutation
-    train_idx, val_idx = perm[:n_train].to(device), perm[n_train:].to(device)
+    idx_dev = torch.device("cpu") if stream is not None else device
+    train_idx, val_idx = perm[:n_train].to(idx_dev), perm[n_train:].to(idx_dev)
     print(f"Unlabeled pretrain split: {n_train} train, {n_val} val ({val_split * 100:.1f}% validation)")
 
     augment = fraction < 1.0  # the reference's quirk: see the module docstring
     aug_gen = torch.Generator(device=device).manual_seed(seed + 7)
-    finish = (lambda x: augment_batch(x, aug_gen).contiguous()) if augment else (lambda x: x.contiguous())
+
+    def finish(x: torch.Tensor) -> torch.Tensor:
+        if not augment:
+            return x.contiguous()  # uint8 stays uint8: normalised inside the engine
+        x = normalize_u8(x) if x.dtype == torch.uint8 else x  # the resampling needs floats
+        return augment_batch(x, aug_gen).contiguous()
+
+    def serve(order: torch.Tensor) -> Iterator[torch.Tensor]:
+        if stream is not None:
+            for x in stream.batches(order):
+                yield finish(x)
+        else:
+            for i in range(0, order.numel(), batch):  # no drop_last, like the reference
+                yield finish(fetch(order[i:i + batch]))
 
     def train_batches(epoch: int) -> Iterator[torch.Tensor]:
         g = torch.Generator().manual_seed(seed + 1000 + epoch)  # DataLoader(shuffle=True): a fresh order per epoch
-        order = train_idx[torch.randperm(n_train, generator=g).to(device)]
-        for i in range(0, n_train, batch):  # no drop_last, like the reference
-            yield finish(fetch(order[i:i + batch]))
+        return serve(train_idx[torch.randperm(n_train, generator=g).to(train_idx.device)])
 
     def val_batches() -> Iterator[torch.Tensor]:
-        for i in range(0, n_val, batch):
-            yield finish(fetch(val_idx[i:i + batch]))
+        return serve(val_idx)
 
     return train_batches, val_batches

@@ -443,7 +443,13 @@ class MaskedAutoencoder(nn.Module):
         if images.dim() != 4 or images.shape[1] != self.in_chans or images.shape[2] != self.image_size or images.shape[3] != self.image_size:
             raise ValueError(f"Input size {tuple(images.shape)} doesn't match model "
                              f"(B, {self.in_chans}, {self.image_size}, {self.image_size})")  # timm PatchEmbed assert
+        if images.dtype == torch.uint8:  # raw pixels: ToTensor + Normalize(.5,.5) happens inside the pixel-reading kernels
+            return images.contiguous()
         return images.to(dtype=torch.float32).contiguous()
+
+    @staticmethod
+    def _img_dt(images: torch.Tensor) -> int:
+        return _lib.MAE_U8 if images.dtype == torch.uint8 else _lib.MAE_F32
 
     def _check_idx(self, idx: torch.Tensor, batch: int, what: str) -> torch.Tensor:
         if idx.dim() != 2 or idx.shape[0] != batch:
@@ -459,7 +465,7 @@ class MaskedAutoencoder(nn.Module):
         ws = self._ws(B, k)
         self._gen_enc += 1; self._gen_dec += 1  # enc_norm, which the decoder's backward reads, is rewritten too
         out = torch.empty(B, k, self._dims["embed_dim"], dtype=torch.float32, device=dev)
-        check(lib.mae_engine_forward_encoder(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images),
+        check(lib.mae_engine_forward_encoder(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images), self._img_dt(images),
                                             _ptr(idx_keep), B, k, _ptr(ws), ws.numel(), _ptr(out), _stream(dev)))
         return out
 
@@ -508,7 +514,8 @@ class MaskedAutoencoder(nn.Module):
         dev = self._require_cuda()
         B, m = idx_mask.shape
         target = torch.empty(B, m, self.patch_dim, dtype=torch.float32, device=dev)
-        check(lib.mae_patchify_gather(_ptr(images, torch.float32), _ptr(idx_mask, torch.int64), B, self.in_chans, self.image_size,
+        images = self._check_images(images)
+        check(lib.mae_patchify_gather(_ptr(images), self._img_dt(images), _ptr(idx_mask, torch.int64), B, self.in_chans, self.image_size,
                                      self.patch_size, m, _ptr(target), _stream(dev)))
         return target
 
@@ -519,8 +526,8 @@ class MaskedAutoencoder(nn.Module):
         self._gen_enc += 1; self._gen_dec += 1
         h, w = self._engine.handle, self._weights()
         x_pred = torch.empty(B, m, self.patch_dim, dtype=torch.float32, device=dev)
-        check(lib.mae_engine_forward_encoder(h, _ptr(self._arena), _ptr(w), _ptr(images), _ptr(idx_keep), B, k, _ptr(ws), ws.numel(),
-                                            None, _stream(dev)))
+        check(lib.mae_engine_forward_encoder(h, _ptr(self._arena), _ptr(w), _ptr(images), self._img_dt(images), _ptr(idx_keep), B, k, _ptr(ws),
+                                            ws.numel(), None, _stream(dev)))
         check(lib.mae_engine_forward_decoder(h, _ptr(self._arena), _ptr(w), None, _ptr(idx_keep), _ptr(idx_mask), B, k, m, _ptr(ws),
                                             ws.numel(), _ptr(x_pred), _stream(dev)))
         return x_pred, self.patchify_gather(images, idx_mask)
@@ -576,13 +583,13 @@ class MaskedAutoencoder(nn.Module):
             keep = torch.empty(B, k, dtype=torch.int64, device=dev)
             mask = torch.empty(B, L - k, dtype=torch.int64, device=dev)
         if ready_events is None:
-            check(lib.mae_engine_loss_and_grads(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images), _ptr(noise),
-                                               B, k, float(grad_scale), _ptr(ws), ws.numel(), _ptr(self.flat_grads), _ptr(loss, torch.float32),
+            check(lib.mae_engine_loss_and_grads(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images), self._img_dt(images),
+                                               _ptr(noise), B, k, float(grad_scale), _ptr(ws), ws.numel(), _ptr(self.flat_grads), _ptr(loss, torch.float32),
                                                _ptr(keep), _ptr(mask), _stream(dev)))
         else:
             evs = (C.c_void_p * len(ready_events))(*[C.c_void_p(ev.cuda_event) if ev is not None else C.c_void_p(0) for ev in ready_events])
             check(lib.mae_engine_loss_and_grads_phased(self._engine.handle, _ptr(self._arena), _ptr(self._weights()), _ptr(images),
-                                                      _ptr(noise), B, k, float(grad_scale), _ptr(ws), ws.numel(), _ptr(self.flat_grads),
+                                                      self._img_dt(images), _ptr(noise), B, k, float(grad_scale), _ptr(ws), ws.numel(), _ptr(self.flat_grads),
                                                       _ptr(loss, torch.float32), _ptr(keep), _ptr(mask), evs, len(ready_events), _stream(dev)))
         return (loss, keep, mask) if return_indices else loss
 

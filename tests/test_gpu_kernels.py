@@ -73,7 +73,7 @@ def test_patchify_gather(dev, B, C, img, p, m):
     patches = torch.einsum("nchpwq->nhwpqc", patches).reshape(B, n, p * p * C)
     ref = torch.gather(patches, 1, (idx - 1).clamp(min=0).unsqueeze(-1).expand(-1, -1, p * p * C))
     out = torch.empty(B, m, p * p * C, device=dev)
-    check(lib.mae_patchify_gather(_ptr(dv(images)), _ptr(dv(idx)), B, C, img, p, m, _ptr(out), stream(dev)))
+    check(lib.mae_patchify_gather(_ptr(dv(images)), F32, _ptr(dv(idx)), B, C, img, p, m, _ptr(out), stream(dev)))
     assert torch.equal(out.cpu(), ref)
 
 
