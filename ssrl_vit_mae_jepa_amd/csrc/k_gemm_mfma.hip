@@ -404,7 +404,11 @@ __device__ __forceinline__ void tn_glds16(const bf16* src, char* dst) {
 }
 template <int N_>
 __device__ __forceinline__ void tn_wait_vm() {
+#ifdef MAE_DBG_VMCNT0  // see wait_vm() in k_gemm_mfma2.hip: the all-drained build the counted waits are checked against
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+#endif
 }
 
 __global__ void __launch_bounds__(512, 2) gemm_tn2_kernel(const bf16* __restrict__ dY, const bf16* __restrict__ X, int64_t M, int N, int K,

@@ -51,7 +51,11 @@ __device__ __forceinline__ void ld8(const bf16* p, f32x4& a, f32x4& b) { unpack8
 // lines in L2 until eviction, which both frees L2 for the A / W re-reads and spreads the write traffic over the tile loop
 // (measured: fc1 + GELU forward 220 -> 170 us, decoder fc1 332 -> 242 us).
 // (a per-launch runtime choice between the two store forms was tried: the uniform branch per store cost 1.1 ms per step)
+#ifdef MAE_DBG_EPI_PLAINSTORE
+template <class V> __device__ __forceinline__ void stream_store(V v, V* p) { *p = v; }
+#else
 template <class V> __device__ __forceinline__ void stream_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
+#endif
 __device__ __forceinline__ void st8(float* p, const f32x4& a, const f32x4& b) {
   stream_store(a, reinterpret_cast<f32x4*>(p));
   stream_store(b, reinterpret_cast<f32x4*>(p + 4));
@@ -71,9 +75,18 @@ __device__ __forceinline__ int64_t xcd_remap2(int64_t bid, int64_t nb) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// The counted waits below assume (i) vector-memory operations of a wave retire in issue order (LDS-DMA loads and the
+// epilogue's stores share one counter, MI355X_MICROARCH: "loads, stores, atomics and LDS-DMA count together, in issue
+// order") and (ii) E equals the number of store instructions the compiler emits per wave and tile.  -DMAE_DBG_VMCNT0
+// builds the same kernel with every wait drained to zero: tests/test_gpu_kernels.py compares the two builds bit for bit
+// (tools/build_dbg_lib.sh vmcnt0), so a miscounted wait shows up as a difference instead of a rare wrong tile.
 template <int N>
 __device__ __forceinline__ void wait_vm() {
+#ifdef MAE_DBG_VMCNT0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
 }
 
 }  // namespace
@@ -257,7 +270,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
 #else
           if (m < M) {
 #endif
+#ifdef MAE_DBG_EPI_LINEAR
+            // timing probe only (wrong layout): every store instruction of a wave writes 1 KiB of whole 128-byte lines
+            const int64_t o = ((int64_t)t * (BM2 * BN)) + (((wave * MI + mi) * (NI / 2) + j) * 64 + lane) * 8;
+#else
             const int64_t o = m * N + n0 + wn * (NI * 16) + nl;
+#endif
             f32x4 v0 = acc[mi][2 * j] + b0, v1 = acc[mi][2 * j + 1] + b1;
             if (MODE == MAE_EPI_GELU) {
               f32x4 a0, a1;
@@ -286,10 +304,21 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
                 v0[r] = to_f(from_f<TO>(v0[r]));
                 v1[r] = to_f(from_f<TO>(v1[r]));
               }
+#if defined(MAE_DBG_EPI_NOGELU)   // epilogue ablation builds (tools/run_epi_ablation.sh): timing probes, wrong values
+              a0 = v0; a1 = v1; g0 = v0 * 0.5f; g1 = v1 * 0.5f;
+#else
               gelu_fast_pair(v0, a0, g0);
               gelu_fast_pair(v1, a1, g1);
+#endif
+#if defined(MAE_DBG_EPI_NOSTORE)
+              asm volatile("" ::"v"(g0), "v"(g1), "v"(a0), "v"(a1));
+#elif defined(MAE_DBG_EPI_ONESTORE)
+              asm volatile("" ::"v"(g0), "v"(g1));
+              st8(out2 + o, a0, a1);
+#else
               st8(out + o, g0, g1);
               st8(out2 + o, a0, a1);
+#endif
             } else if (MODE == MAE_EPI_MUL) {
               f32x4 q0, q1;
               if (PREF) unpack8(qa[PREF ? j : 0][PREF ? mi : 0], q0, q1);

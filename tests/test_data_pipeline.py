@@ -58,7 +58,8 @@ def test_uint8_pixels_in_the_engine_equal_normalised_floats(dev, img, p, C, B):
     assert torch.equal(model.patchify_gather(u8.to(dev), mask).cpu(), aux["target"])                    # bit-exact target
     assert torch.equal(model.patchify_gather(u8.to(dev), mask), model.patchify_gather(f32.to(dev), mask))
     assert abs(loss_u8.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
-    assert torch.equal(loss_u8, loss_f32) and torch.equal(g_u8, model.flat_grads)                       # same bits as the fp32-image path
+    # same gradient bits as the fp32-image path (the scalar loss is summed over a different grid: equal to rounding)
+    assert abs(loss_u8.item() - loss_f32.item()) <= 1e-6 * abs(loss_f32.item()) and torch.equal(g_u8, model.flat_grads)
     with torch.no_grad():
         assert torch.equal(model.forward_encoder(u8.to(dev), keep), model.forward_encoder(f32.to(dev), keep))
         feats = model.encoder.vit.forward_features(u8.to(dev))                                           # class token + every patch
@@ -85,7 +86,7 @@ def test_uint8_full_size_batch_2000_matches_float_images(dev):
     a = model.loss_and_grads(u8, noise).clone()
     ga = model.flat_grads.clone()
     b = model.loss_and_grads(D.normalize_u8(u8), noise)
-    assert torch.equal(a, b) and torch.equal(ga, model.flat_grads)
+    assert abs(a.item() - b.item()) <= 1e-5 * abs(b.item()) and torch.equal(ga, model.flat_grads)  # 84 M squared errors summed over two grids
 
 
 @pytest.mark.gpu

@@ -270,3 +270,70 @@ def test_attention_fwd_bwd(dev, B, T, H, hd, dt):
     dqkv = torch.full((B, T, 3 * H * hd), float("nan"), dtype=TDT[dt], device=dev)
     check(lib.mae_attention_bwd(_ptr(dv(qkv)), _ptr(out), _ptr(dv(do)), _ptr(lse), B, T, H, hd, dt, _ptr(dqkv), stream(dev)))
     assert rel_err(dqkv.float(), qr.grad) < (5e-5 if dt == F32 else 2e-2)
+
+
+# ---------------------------------------------------------------------------------- hand-counted vmcnt waits
+def test_counted_vmcnt_waits_equal_the_all_drained_build(dev, tmp_path):
+    """The persistent NT GEMM and the wgrad ring wait with hand-counted `s_waitcnt vmcnt(N)` (next stage's DMAs + the previous
+    tile's epilogue stores stay in flight).  An alternate build with every wait drained to zero (-DMAE_DBG_VMCNT0) must
+    produce the same bits for every epilogue mode, both output types, partial tiles and nk <= 2: a miscounted wait would
+    read a stage before its DMA has landed."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    dbg = root / "ssrl_vit_mae_jepa_amd" / "lib_dbg_vmcnt0" / "libmae_hip.so"
+    if not dbg.exists():
+        subprocess.run(["bash", str(root / "tools" / "build_dbg_lib.sh"), "vmcnt0"], check=True)
+    script = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from tests.util import BF16, F32, TDT, check, lib, stream, _ptr
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(11)
+MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5}
+out = {}
+# (M, N, K): full tiles, a ragged last tile, several tiles per CU, nk = 3 / 6 / 24, N multiples of 192 and of 128
+for M, N, K in [(70000, 1536, 384), (4099, 384, 192), (33000, 1152, 384), (9000, 384, 1536), (20000, 512, 256), (300, 192, 192)]:
+    A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    W = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.rand(N, device=dev, generator=g)
+    for epi in MODE:
+        for odt in (BF16, F32):
+            if epi == "resid" and odt == BF16:
+                continue
+            aux = None
+            if epi == "resid":
+                aux = torch.rand(M, N, device=dev, generator=g)
+            elif epi in ("dgelu", "mul"):
+                aux = (torch.rand(M, N, device=dev, generator=g) * 4 - 2).to(TDT[odt])
+            o = torch.zeros(M, N, dtype=TDT[odt], device=dev); o2 = torch.zeros_like(o)
+            for rep in range(3):  # back-to-back launches: stages and stores of the previous launch still in flight
+                check(lib.mae_linear_fwd(_ptr(A), _ptr(W), _ptr(bias), M, N, K, BF16, MODE[epi], odt, _ptr(o),
+                                         _ptr(o2) if epi in ("gelu", "gelu_grad") else None, _ptr(aux) if aux is not None else None, stream(dev)))
+            out[f"nt/{M}x{N}x{K}/{epi}/{odt}"] = (o.float().cpu(), o2.float().cpu())
+    dW = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
+    dY = (torch.rand(M, N, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    scratch = torch.empty(max(1, lib.mae_linear_wgrad_scratch_bytes(M, N, K)), dtype=torch.uint8, device=dev)
+    for rep in range(2):
+        check(lib.mae_linear_wgrad(_ptr(dY), _ptr(A), M, N, K, BF16, _ptr(dW), _ptr(db), _ptr(scratch), stream(dev)))
+    out[f"tn/{M}x{N}x{K}"] = (dW.cpu(), db.cpu())
+torch.cuda.synchronize()
+torch.save(out, sys.argv[1])
+""" % str(root)
+    res = {}
+    for name, libpath in (("product", None), ("vmcnt0", dbg)):
+        env = dict(os.environ)
+        env.pop("MAE_HIP_LIB", None)
+        if libpath is not None:
+            env["MAE_HIP_LIB"] = str(libpath)
+        f = tmp_path / f"{name}.pt"
+        r = subprocess.run([sys.executable, "-c", script, str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        res[name] = torch.load(f, weights_only=True)
+    assert set(res["product"]) == set(res["vmcnt0"]) and len(res["product"]) > 60
+    for k, (a, b) in res["product"].items():
+        a2, b2 = res["vmcnt0"][k]
+        assert torch.equal(a, a2) and torch.equal(b, b2), k
+        assert torch.isfinite(a).all() and float(a.abs().sum()) > 0, k
