@@ -56,7 +56,9 @@ typedef struct mae_config {
   int32_t decoder_embed_dim, decoder_depth, decoder_num_heads;
   int32_t mlp_ratio;      /* timm default 4 */
   int32_t act_dtype;      /* MAE_F32 | MAE_BF16 */
-  int32_t reserved[5];
+  int32_t pred_dim;       /* width of the prediction head: 0 = patch_size^2 * in_chans (MAE pixel targets);
+                             embed_dim for the I-JEPA engine (latent targets), where the "decoder" is the predictor */
+  int32_t reserved[4];
 } mae_config_t;
 
 typedef struct mae_engine mae_engine_t;
@@ -187,6 +189,36 @@ int mae_engine_loss_and_grads_phased(mae_engine_t* e, const float* params, const
 int mae_engine_optimizer_step(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
                               void* wcache, float lr, float beta1, float beta2, float eps, float weight_decay,
                               float max_norm, int64_t step, float* stats_out, float* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * I-JEPA step (BASELINE.json configs[2] and [4]).  The reference has NO I-JEPA code ("JEPA" only in README.md:1,9 and
+ * pyproject.toml:2), so nothing here replaces a reference function: the specification is DESIGN.md section "I-JEPA"
+ * (I-JEPA paper), built from the same ViT pieces.  The engine must be created with pred_dim = embed_dim; its
+ * "decoder" tensors are the predictor.  Token ids are patch tokens 1 .. N (0, the class token, is not used).
+ *   idx_context (batch, num_context) int64: context tokens of every image (same count for all: truncated to the minimum);
+ *   idx_target  (batch, num_blocks, block_tokens) int64: the target blocks;
+ *   target_params / target_wcache: the EMA target encoder, an arena of the same layout (only the encoder part is read);
+ *   loss over all batch * num_blocks * block_tokens * D elements between predictor output and
+ *   layer_norm(target_encoder(images))[targets] (no affine, eps 1e-5); loss_kind MAE_LOSS_MSE | MAE_LOSS_SMOOTH_L1.
+ * grads == NULL: compute the targets only.  h_out / pred_out: optional fp32 copies (batch*num_blocks*block_tokens, D).
+ * ready_events: as mae_engine_loss_and_grads_phased (may be NULL, then num_ready is ignored). */
+enum { MAE_LOSS_MSE = 0, MAE_LOSS_SMOOTH_L1 = 1 };
+int64_t mae_engine_jepa_workspace_bytes(const mae_engine_t* e, int32_t batch, int32_t num_context, int32_t num_blocks,
+                                        int32_t block_tokens);
+int mae_engine_jepa_loss_and_grads(mae_engine_t* e, const float* params, const void* wcache, const float* target_params,
+                                   const void* target_wcache, const void* images, int32_t image_dtype,
+                                   const int64_t* idx_context, const int64_t* idx_target, int32_t batch,
+                                   int32_t num_context, int32_t num_blocks, int32_t block_tokens, int32_t loss_kind,
+                                   float grad_scale, void* workspace, int64_t workspace_bytes, float* grads,
+                                   float* loss_out, float* h_out, float* pred_out, void* const* ready_events,
+                                   int32_t num_ready, void* stream);
+/* mae_engine_optimizer_step with the EMA update of the target encoder fused into the AdamW sweep:
+ * target[0 .. encoder_grad_elems) = m * target + (1 - m) * params_new (+ the bf16 operand copy in target_wcache).
+ * max_norm = +inf disables clipping (I-JEPA trains unclipped). */
+int mae_engine_optimizer_step_ema(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq,
+                                  void* wcache, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  float max_norm, int64_t step, float* stats_out, float* scratch, float* target_params,
+                                  void* target_wcache, float ema_momentum, void* stream);
 
 /* Per-kernel-class device timing with HIP events on `stream` (bench.py roofline): enable, run
  * steps, then read.  kind: index into mae_engine_timer_name().  Reading synchronises the events. */

@@ -7,5 +7,6 @@ Importing this package without the built library raises ImportError: there is no
 from ._lib import MaeHipError, LIB_PATH  # noqa: F401  (import fails loudly when the extension is missing)
 from .mae import MaskedAutoencoder, Engine  # noqa: F401
 from .training import MAEPretrainModule, lr_lambda, mask_ratio_at  # noqa: F401
+from .jepa import IJEPA, IJEPAPretrainModule, sample_block_masks  # noqa: F401
 
-__all__ = ["MaskedAutoencoder", "MAEPretrainModule", "Engine", "MaeHipError", "lr_lambda", "mask_ratio_at", "LIB_PATH"]
+__all__ = ["MaskedAutoencoder", "MAEPretrainModule", "IJEPA", "IJEPAPretrainModule", "sample_block_masks", "Engine", "MaeHipError", "lr_lambda", "mask_ratio_at", "LIB_PATH"]

@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("MAE_HIP_LIB") or _HERE / "lib" / "libmae_hip.so"
 
 MAE_F32, MAE_BF16, MAE_U8 = 0, 1, 2
 PARAM_TRAINABLE, PARAM_FROZEN, PARAM_UNUSED, PARAM_MATRIX = 1, 2, 4, 8
+LOSS_MSE, LOSS_SMOOTH_L1 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL = 0, 1, 2, 3, 4, 5
 ABI_VERSION = 2
 
@@ -23,8 +24,8 @@ ABI_VERSION = 2
 class MaeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "image_size", "patch_size", "in_chans", "embed_dim", "depth", "num_heads",
-        "decoder_embed_dim", "decoder_depth", "decoder_num_heads", "mlp_ratio", "act_dtype")] + [
-        ("reserved", C.c_int32 * 5)]
+        "decoder_embed_dim", "decoder_depth", "decoder_num_heads", "mlp_ratio", "act_dtype", "pred_dim")] + [
+        ("reserved", C.c_int32 * 4)]
 
 
 class MaeHipError(RuntimeError):
@@ -72,6 +73,10 @@ SIGNATURES = {
     "mae_engine_grad_ready_points": (_i32, [_vp, _pp(_i64), _i32]),
     "mae_engine_loss_and_grads_phased": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _pp(_vp), _i32, _vp]),
     "mae_engine_optimizer_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _vp, _vp]),
+    "mae_engine_jepa_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32, _i32]),
+    "mae_engine_jepa_loss_and_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64,
+                                                 _vp, _vp, _vp, _vp, _pp(_vp), _i32, _vp]),
+    "mae_engine_optimizer_step_ema": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _f32, _vp]),
     "mae_engine_timers_enable": (C.c_int, [_vp, _i32]),
     "mae_engine_timer_count": (_i32, [_vp]),
     "mae_engine_timer_name": (C.c_char_p, [_vp, _i32]),

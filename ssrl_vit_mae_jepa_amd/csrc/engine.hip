@@ -60,6 +60,7 @@ struct mae_engine {
   mae_config_t cfg;
   int act = MAE_F32;
   int D, depth, H, Dd, dd, Hd, P, L, G, C, img, p, mlp;
+  int PO;  // width of the prediction head: P (MAE pixels) or cfg.pred_dim (I-JEPA: the encoder width)
   std::vector<ParamInfo> params;
   int64_t arena_elems = 0, trainable_elems = 0, trans_elems = 0;
   int i_enc_mask, i_cls, i_pos, i_patch_w, i_patch_b, i_norm_w, i_norm_b;
@@ -118,6 +119,7 @@ struct LayerBufs {
 
 struct Plan {
   int B, k, m;
+  int dec_B, dec_T;  // decoder / predictor attention batch and sequence length: (B, L) for MAE, (B * nblk, k + m) for I-JEPA
   int64_t Me, Md, Mp;
   int64_t keep32, mask32, inv, pred_rows;
   int64_t patchA;
@@ -131,10 +133,12 @@ struct Plan {
   int64_t total;
 };
 
-static Plan make_plan(const mae_engine* e, int B, int k) {
+// dec_B sequences of dec_T tokens go through the decoder stack, m_seq of them per sequence reach the prediction head
+static Plan make_plan_ex(const mae_engine* e, int B, int k, int dec_B, int dec_T, int m_seq) {
   Plan pl;
-  pl.B = B; pl.k = k; pl.m = e->L - k;
-  pl.Me = (int64_t)B * k; pl.Md = (int64_t)B * e->L; pl.Mp = (int64_t)B * pl.m;
+  pl.B = B; pl.k = k; pl.m = m_seq;
+  pl.dec_B = dec_B; pl.dec_T = dec_T;
+  pl.Me = (int64_t)B * k; pl.Md = (int64_t)dec_B * dec_T; pl.Mp = (int64_t)dec_B * m_seq;
   const int64_t as = (int64_t)dtype_size(e->act);
   int64_t off = 0;
   auto take = [&](int64_t bytes) { const int64_t o = off; off += round_up(std::max<int64_t>(bytes, 4), 256); return o; };
@@ -144,6 +148,7 @@ static Plan make_plan(const mae_engine* e, int B, int k) {
   pl.pred_rows = take(pl.Mp * 4);
   pl.patchA = take(pl.Me * e->P * as);
   auto layers = [&](int n, int64_t M, int d, int heads, int T, std::vector<int64_t>& xs, std::vector<LayerBufs>& ls) {
+    const int64_t seqs = M / std::max(T, 1);
     xs.resize(n + 1);
     ls.resize(n);
     xs[0] = take(M * d * 4);
@@ -151,7 +156,7 @@ static Plan make_plan(const mae_engine* e, int B, int k) {
       LayerBufs& b = ls[i];
       b.ln1 = take(M * d * as); b.mean1 = take(M * 4); b.rstd1 = take(M * 4);
       b.qkv = take(M * 3 * d * as);
-      b.lse = take((int64_t)B * heads * T * 4);
+      b.lse = take(seqs * heads * T * 4);
       b.att = take(M * d * as);
       b.x_mid = take(M * d * 4);
       b.ln2 = take(M * d * as); b.mean2 = take(M * 4); b.rstd2 = take(M * 4);
@@ -163,15 +168,15 @@ static Plan make_plan(const mae_engine* e, int B, int k) {
   layers(e->depth, pl.Me, e->D, e->H, k, pl.enc_x, pl.enc);
   pl.enc_norm = take(pl.Me * e->D * as); pl.enc_mean = take(pl.Me * 4); pl.enc_rstd = take(pl.Me * 4);
   pl.xdec = take(pl.Me * e->Dd * as);
-  layers(e->dd, pl.Md, e->Dd, e->Hd, e->L, pl.dec_x, pl.dec);
+  layers(e->dd, pl.Md, e->Dd, e->Hd, dec_T, pl.dec_x, pl.dec);
   pl.dec_norm = take(std::max<int64_t>(pl.Mp, 1) * e->Dd * as);
   pl.dec_mean = take(std::max<int64_t>(pl.Mp, 1) * 4); pl.dec_rstd = take(std::max<int64_t>(pl.Mp, 1) * 4);
-  pl.pred = take(std::max<int64_t>(pl.Mp, 1) * e->P * 4);
+  pl.pred = take(std::max<int64_t>(pl.Mp, 1) * e->PO * 4);
   // backward scratch, shared by the decoder and encoder sweeps
   const int64_t R = std::max(pl.Me * e->D, pl.Md * e->Dd);
   pl.branch_a = take(R * as);
   pl.branch_b = take(R * as);
-  pl.dpred = take(std::max<int64_t>(pl.Mp, 1) * e->P * as);
+  pl.dpred = take(std::max<int64_t>(pl.Mp, 1) * e->PO * as);
   pl.d_decn = take(std::max<int64_t>(pl.Mp, 1) * e->Dd * as);
   pl.dres = take(R * 4);
   pl.dres_c = take(R * as);
@@ -189,12 +194,13 @@ static Plan make_plan(const mae_engine* e, int B, int k) {
   auto wgs = [&](int64_t M, int N, int K) { wg = std::max(wg, linear_wgrad_scratch_bytes(M, N, K)); };
   wgs(pl.Me, 3 * e->D, e->D); wgs(pl.Me, e->mlp * e->D, e->D); wgs(pl.Me, e->D, e->mlp * e->D); wgs(pl.Me, e->D, e->D);
   wgs(pl.Md, 3 * e->Dd, e->Dd); wgs(pl.Md, e->mlp * e->Dd, e->Dd); wgs(pl.Md, e->Dd, e->mlp * e->Dd); wgs(pl.Md, e->Dd, e->Dd);
-  wgs(pl.Me, e->D, e->P); wgs(pl.Me, e->Dd, e->D); wgs(std::max<int64_t>(pl.Mp, 1), e->P, e->Dd);
+  wgs(pl.Me, e->D, e->P); wgs(pl.Me, e->Dd, e->D); wgs(std::max<int64_t>(pl.Mp, 1), e->PO, e->Dd);
   pl.wgrad_scratch = take(wg);
   pl.loss_scratch = take(4096 * 4);
   pl.total = off;
   return pl;
 }
+static Plan make_plan(const mae_engine* e, int B, int k) { return make_plan_ex(e, B, k, B, e->L, e->L - k); }
 
 // ---------------------------------------------------------------------------------------------------
 // timers
@@ -424,19 +430,32 @@ static int forward_encoder_impl(const Ctx& c, const Plan& pl, const void* images
   return 0;
 }
 
-// needs keep32 / mask32 already in the workspace
-static int forward_decoder_impl(const Ctx& c, const Plan& pl, float* x_pred_out) {
+// I-JEPA predictor input (no counterpart in the reference; spec in DESIGN.md): per image nblk sequences
+// [k context tokens | m mask tokens of target block i], position rows gathered by token id
+struct JepaSeq {
+  const int32_t* ctx32;  // (B, k) context token ids
+  const int32_t* tgt32;  // (B, nblk, m) target token ids
+  int nblk;
+};
+
+// needs keep32 / mask32 already in the workspace (MAE) or the token lists of `jp` (I-JEPA)
+static int forward_decoder_impl(const Ctx& c, const Plan& pl, float* x_pred_out, const JepaSeq* jp = nullptr) {
   mae_engine* e = c.e; hipStream_t s = c.s;
   MAE_REQUIRE(pl.m > 0, "forward_decoder: nothing is masked (num_keep == sequence_length)");
-  MAE_TRY(launch_build_inverse(c.buf<int32_t>(pl.keep32), pl.B, pl.k, e->L, c.buf<int32_t>(pl.inv), s));
-  MAE_TRY(launch_build_row_map(c.buf<int32_t>(pl.mask32), pl.B, pl.m, e->L, c.buf<int32_t>(pl.pred_rows), s));
   MAE_TRY(linear(c, c.buf<>(pl.enc_norm), e->i_de_w, e->i_de_b, pl.Me, e->Dd, e->D, MAE_EPI_NONE, c.act, c.buf<>(pl.xdec), nullptr, nullptr));
-  RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_decoder_assemble(c.buf<>(pl.xdec), c.act, c.buf<int32_t>(pl.inv), c.P(e->i_dec_mask), c.P(e->i_dec_pos), pl.B, pl.k, e->L, e->Dd, c.buf<float>(pl.dec_x[0]), s));
+  if (jp) {
+    MAE_TRY(launch_build_tail_row_map(pl.dec_B, pl.dec_T, pl.m, c.buf<int32_t>(pl.pred_rows), s));
+    RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_predictor_assemble(c.buf<>(pl.xdec), c.act, jp->ctx32, jp->tgt32, c.P(e->i_dec_mask), c.P(e->i_dec_pos), pl.B, pl.k, jp->nblk, pl.m, e->L, e->Dd, c.buf<float>(pl.dec_x[0]), s));
+  } else {
+    MAE_TRY(launch_build_inverse(c.buf<int32_t>(pl.keep32), pl.B, pl.k, e->L, c.buf<int32_t>(pl.inv), s));
+    MAE_TRY(launch_build_row_map(c.buf<int32_t>(pl.mask32), pl.B, pl.m, e->L, c.buf<int32_t>(pl.pred_rows), s));
+    RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_decoder_assemble(c.buf<>(pl.xdec), c.act, c.buf<int32_t>(pl.inv), c.P(e->i_dec_mask), c.P(e->i_dec_pos), pl.B, pl.k, e->L, e->Dd, c.buf<float>(pl.dec_x[0]), s));
+  }
   for (int i = 0; i < e->dd; ++i)
-    MAE_TRY(block_forward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.B, e->L, i ? pl.dec[i - 1].x_mid : 0, i > 0, pl.dec_x[i]));
+    MAE_TRY(block_forward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.dec_B, pl.dec_T, i ? pl.dec[i - 1].x_mid : 0, i > 0, pl.dec_x[i]));
   // decoder_norm on the masked rows only; the residual add of the last MLP branch is done for exactly those rows
   RUN(TK_LN_FWD, 0, pl.Mp * e->Dd * (8 + 2 * c.as), launch_layernorm_fwd(c.buf<float>(pl.dec[e->dd - 1].x_mid), c.buf<>(pl.branch_b), c.buf<float>(pl.dec_x[e->dd]), c.buf<int32_t>(pl.pred_rows), c.P(e->i_dn_w), c.P(e->i_dn_b), 1e-6f, pl.Mp, e->Dd, c.act, c.buf<>(pl.dec_norm), c.buf<float>(pl.dec_mean), c.buf<float>(pl.dec_rstd), s));
-  MAE_TRY(linear(c, c.buf<>(pl.dec_norm), e->i_pred_w, e->i_pred_b, pl.Mp, e->P, e->Dd, MAE_EPI_NONE, MAE_F32, x_pred_out ? (void*)x_pred_out : c.buf<>(pl.pred), nullptr, nullptr));
+  MAE_TRY(linear(c, c.buf<>(pl.dec_norm), e->i_pred_w, e->i_pred_b, pl.Mp, e->PO, e->Dd, MAE_EPI_NONE, MAE_F32, x_pred_out ? (void*)x_pred_out : c.buf<>(pl.pred), nullptr, nullptr));
   return 0;
 }
 
@@ -470,21 +489,24 @@ static int backward_end(const Ctx& c) {
 
 // Decoder half: dpred (act dtype) must already sit in the workspace; leaves d(x_encoded) (act dtype) in pl.d_ln and
 // every decoder gradient in its arena range [offset(decoder.mask_token), trainable_elems).
-static int backward_decoder_impl(const Ctx& c, const Plan& pl) {
+static int backward_decoder_impl(const Ctx& c, const Plan& pl, const JepaSeq* jp = nullptr) {
   mae_engine* e = c.e; hipStream_t s = c.s;
   float* dres = c.buf<float>(pl.dres);
   void* dres_c = c.buf<>(pl.dres_c);
   // prediction head
-  MAE_TRY(wgrad(c, pl, c.buf<>(pl.dpred), c.buf<>(pl.dec_norm), pl.Mp, e->P, e->Dd, e->i_pred_w, e->i_pred_b, DEP_MISC));
-  MAE_TRY(dgrad(c, c.buf<>(pl.dpred), e->i_pred_w, pl.Mp, e->P, e->Dd, MAE_EPI_NONE, c.buf<>(pl.d_decn), nullptr));
+  MAE_TRY(wgrad(c, pl, c.buf<>(pl.dpred), c.buf<>(pl.dec_norm), pl.Mp, e->PO, e->Dd, e->i_pred_w, e->i_pred_b, DEP_MISC));
+  MAE_TRY(dgrad(c, c.buf<>(pl.dpred), e->i_pred_w, pl.Mp, e->PO, e->Dd, MAE_EPI_NONE, c.buf<>(pl.d_decn), nullptr));
   // decoder_norm over the masked rows only: every other row of the residual gradient is zero
   MAE_TRY(await_side(e, DEP_DRESC, s));
   MAE_HIP(hipMemsetAsync(dres, 0, (size_t)pl.Md * e->Dd * 4, s));
   MAE_HIP(hipMemsetAsync(dres_c, 0, (size_t)pl.Md * e->Dd * c.as, s));
   RUN(TK_LN_BWD, 0, pl.Mp * e->Dd * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_decn), c.act, c.buf<float>(pl.dec_x[e->dd]), c.buf<int32_t>(pl.pred_rows), c.P(e->i_dn_w), c.buf<float>(pl.dec_mean), c.buf<float>(pl.dec_rstd), pl.Mp, e->Dd, 0, dres, dres_c, c.Gp(e->i_dn_w), c.Gp(e->i_dn_b), ln_slot(c, pl), s, &e->ln_tab));
   for (int i = e->dd - 1; i >= 0; --i)
-    MAE_TRY(block_backward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.B, e->L, pl.dec_x[i]));
-  RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_decoder_assemble_bwd(dres, c.buf<int32_t>(pl.inv), c.buf<int32_t>(pl.keep32), pl.B, pl.k, e->L, e->Dd, c.act, c.buf<>(pl.d_xdec), c.Gp(e->i_dec_mask), c.buf<float>(pl.split_partial), s));
+    MAE_TRY(block_backward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.dec_B, pl.dec_T, pl.dec_x[i]));
+  if (jp)
+    RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_predictor_assemble_bwd(dres, pl.B, pl.k, jp->nblk, pl.m, e->Dd, c.act, c.buf<>(pl.d_xdec), c.Gp(e->i_dec_mask), c.buf<float>(pl.split_partial), s));
+  else
+    RUN(TK_DATA, 0, pl.Md * e->Dd * 4 + pl.Me * e->Dd * c.as, launch_decoder_assemble_bwd(dres, c.buf<int32_t>(pl.inv), c.buf<int32_t>(pl.keep32), pl.B, pl.k, e->L, e->Dd, c.act, c.buf<>(pl.d_xdec), c.Gp(e->i_dec_mask), c.buf<float>(pl.split_partial), s));
   // decoder_embed
   MAE_TRY(wgrad(c, pl, c.buf<>(pl.d_xdec), c.buf<>(pl.enc_norm), pl.Me, e->Dd, e->D, e->i_de_w, e->i_de_b, DEP_MISC));
   MAE_TRY(dgrad(c, c.buf<>(pl.d_xdec), e->i_de_w, pl.Me, e->Dd, e->D, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
@@ -508,10 +530,10 @@ static int backward_encoder_impl(const Ctx& c, const Plan& pl) {
   return 0;
 }
 
-static int backward_impl(const Ctx& c, const Plan& pl, const float* d_x_encoded_extra = nullptr) {
+static int backward_impl(const Ctx& c, const Plan& pl, const float* d_x_encoded_extra = nullptr, const JepaSeq* jp = nullptr) {
   mae_engine* e = c.e; hipStream_t s = c.s;
   backward_begin(c);
-  MAE_TRY(backward_decoder_impl(c, pl));
+  MAE_TRY(backward_decoder_impl(c, pl, jp));
   if (d_x_encoded_extra) MAE_TRY(launch_add_into(d_x_encoded_extra, c.buf<>(pl.d_ln), c.act, pl.Me * e->D, s));
   MAE_TRY(backward_encoder_impl(c, pl));
   MAE_TRY(backward_end(c));
@@ -544,6 +566,7 @@ extern "C" int mae_engine_create(const mae_config_t* cfg, mae_engine_t** out) {
                 "head dim %d is not supported by the attention kernels (16, 24, 32, 48 or 64): choose num_heads accordingly", hd);
   const int P = cfg->patch_size * cfg->patch_size * cfg->in_chans;
   MAE_REQUIRE(P % 4 == 0, "patch_size^2 * in_chans must be a multiple of 4");
+  MAE_REQUIRE(cfg->pred_dim >= 0 && cfg->pred_dim % 4 == 0, "pred_dim must be 0 (pixels) or a multiple of 4");
   mae_engine* e = new mae_engine();
   e->cfg = *cfg;
   e->act = cfg->act_dtype;
@@ -552,6 +575,7 @@ extern "C" int mae_engine_create(const mae_config_t* cfg, mae_engine_t** out) {
   e->C = cfg->in_chans; e->img = cfg->image_size; e->p = cfg->patch_size;
   e->G = e->img / e->p; e->L = e->G * e->G + 1; e->P = P;
   e->mlp = cfg->mlp_ratio > 0 ? cfg->mlp_ratio : 4;
+  e->PO = cfg->pred_dim > 0 ? cfg->pred_dim : P;
   const int T = MAE_PARAM_TRAINABLE, M = MAE_PARAM_TRAINABLE | MAE_PARAM_MATRIX;
   // state_dict order
   e->i_enc_mask = add_param(e, "encoder.mask_token", {1, 1, e->D}, MAE_PARAM_UNUSED);
@@ -569,8 +593,8 @@ extern "C" int mae_engine_create(const mae_config_t* cfg, mae_engine_t** out) {
   for (int i = 0; i < e->dd; ++i) e->dec.push_back(add_block(e, "decoder.decoder_blocks." + std::to_string(i), e->Dd, e->mlp));
   e->i_dn_w = add_param(e, "decoder.decoder_norm.weight", {e->Dd}, T);
   e->i_dn_b = add_param(e, "decoder.decoder_norm.bias", {e->Dd}, T);
-  e->i_pred_w = add_param(e, "decoder.decoder_pred.weight", {P, e->Dd}, M);
-  e->i_pred_b = add_param(e, "decoder.decoder_pred.bias", {P}, T);
+  e->i_pred_w = add_param(e, "decoder.decoder_pred.weight", {e->PO, e->Dd}, M);
+  e->i_pred_b = add_param(e, "decoder.decoder_pred.bias", {e->PO}, T);
   // arena: trainable-on-path first, then frozen / unused; 64-element alignment
   int64_t off = 0, toff = 0;
   for (auto& pi : e->params)
@@ -691,7 +715,7 @@ extern "C" int mae_engine_backward(mae_engine_t* e, const float* params, const v
   MAE_REQUIRE(num_mask == pl.m && pl.m > 0, "mae_engine_backward: num_mask mismatch");
   hipStream_t s = (hipStream_t)stream;
   Ctx c{e, params, (const char*)wcache, grads, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
-  MAE_TRY(launch_cast(d_pred, MAE_F32, c.buf<>(pl.dpred), e->act, pl.Mp * e->P, s));
+  MAE_TRY(launch_cast(d_pred, MAE_F32, c.buf<>(pl.dpred), e->act, pl.Mp * e->PO, s));
   return backward_impl(c, pl, d_x_encoded_extra);
 }
 
@@ -704,7 +728,7 @@ extern "C" int mae_engine_backward_decoder(mae_engine_t* e, const float* params,
   MAE_REQUIRE(num_mask == pl.m && pl.m > 0, "mae_engine_backward_decoder: num_mask mismatch");
   hipStream_t s = (hipStream_t)stream;
   Ctx c{e, params, (const char*)wcache, grads, (char*)workspace, s, e->act, (int64_t)dtype_size(e->act)};
-  MAE_TRY(launch_cast(d_pred, MAE_F32, c.buf<>(pl.dpred), e->act, pl.Mp * e->P, s));
+  MAE_TRY(launch_cast(d_pred, MAE_F32, c.buf<>(pl.dpred), e->act, pl.Mp * e->PO, s));
   backward_begin(c);
   MAE_TRY(backward_decoder_impl(c, pl));
   MAE_TRY(backward_end(c));
@@ -805,9 +829,113 @@ extern "C" int mae_engine_loss_and_grads_phased(mae_engine_t* e, const float* pa
                              loss_out, idx_keep_out, idx_mask_out, ready_events, stream, "mae_engine_loss_and_grads_phased");
 }
 
-extern "C" int mae_engine_optimizer_step(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,
-                                         float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int64_t step,
-                                         float* stats_out, float* scratch, void* stream) {
+// =====================================================================================================
+// I-JEPA step (BASELINE.json configs[2], [4]; NO reference code -- specification: DESIGN.md section "I-JEPA")
+//   target encoder (EMA weights, every patch token, no gradient) -> parameter-free LayerNorm -> target rows h
+//   context encoder on the context tokens -> predictor on [context | mask tokens of block i] for each target block
+//   -> latent regression loss -> backward through predictor and context encoder
+// The engine's "decoder" tensors are the predictor (decoder_embed = predictor_embed, decoder_pred: Dd -> D, pred_dim = D).
+// =====================================================================================================
+namespace mae {
+
+struct JepaPlan {
+  int64_t ctx32, tgt32, tgt_rows, ones, zeros, stat, h, phase, total;
+  Plan tgt, ctx;   // plans of the two phases, both placed at `phase`
+  int64_t xenc;    // fp32 output of the target encoder, behind the target-phase plan
+};
+
+static JepaPlan make_jepa_plan(const mae_engine* e, int B, int k, int nblk, int m) {
+  JepaPlan jp;
+  const int N = e->L - 1;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) { const int64_t o = off; off += round_up(std::max<int64_t>(bytes, 4), 256); return o; };
+  const int64_t Mp = (int64_t)B * nblk * m;
+  jp.ctx32 = take((int64_t)B * k * 4);
+  jp.tgt32 = take(Mp * 4);
+  jp.tgt_rows = take(Mp * 4);
+  jp.ones = take(e->D * 4);
+  jp.zeros = take(e->D * 4);
+  jp.stat = take(2 * Mp * 4);
+  jp.h = take(Mp * e->D * 4);
+  jp.phase = off;
+  jp.tgt = make_plan_ex(e, B, N, 1, 1, 1);                       // encoder over every patch token; a token-sized decoder stub
+  jp.xenc = round_up(jp.tgt.total, 256);
+  const int64_t tgt_total = jp.xenc + round_up((int64_t)B * N * e->D * 4, 256);
+  jp.ctx = make_plan_ex(e, B, k, B * nblk, k + m, m);
+  jp.total = jp.phase + std::max(tgt_total, jp.ctx.total);
+  return jp;
+}
+
+}  // namespace mae
+
+extern "C" int64_t mae_engine_jepa_workspace_bytes(const mae_engine_t* e, int32_t batch, int32_t num_context, int32_t num_blocks,
+                                                   int32_t block_tokens) {
+  if (!e || batch <= 0 || num_context < 1 || num_context >= e->L || num_blocks < 1 || block_tokens < 1 || block_tokens >= e->L) return -1;
+  return make_jepa_plan(e, batch, num_context, num_blocks, block_tokens).total;
+}
+
+extern "C" int mae_engine_jepa_loss_and_grads(mae_engine_t* e, const float* params, const void* wcache, const float* target_params,
+                                              const void* target_wcache, const void* images, int32_t image_dtype,
+                                              const int64_t* idx_context, const int64_t* idx_target, int32_t batch, int32_t num_context,
+                                              int32_t num_blocks, int32_t block_tokens, int32_t loss_kind, float grad_scale,
+                                              void* workspace, int64_t workspace_bytes, float* grads, float* loss_out, float* h_out,
+                                              float* pred_out, void* const* ready_events, int32_t num_ready, void* stream) {
+  const char* who = "mae_engine_jepa_loss_and_grads";
+  MAE_REQUIRE(e, "%s: null engine", who);
+  MAE_REQUIRE(e->PO == e->D, "%s: the engine was not created with pred_dim = embed_dim (I-JEPA predicts latents of the encoder width)", who);
+  MAE_REQUIRE(params && target_params && images && idx_context && idx_target && workspace && loss_out, "%s: null argument", who);
+  MAE_REQUIRE(e->act == MAE_F32 || (wcache && target_wcache), "%s: bf16 engine needs both weight caches", who);
+  MAE_REQUIRE(batch > 0 && num_context >= 1 && num_blocks >= 1 && block_tokens >= 1 && num_context + block_tokens <= e->L - 1 + block_tokens &&
+              num_context < e->L && block_tokens < e->L, "%s: bad token counts (context %d, blocks %d x %d, %d patches)", who, num_context, num_blocks, block_tokens, e->L - 1);
+  MAE_REQUIRE(loss_kind == MAE_LOSS_MSE || loss_kind == MAE_LOSS_SMOOTH_L1, "%s: loss_kind must be MAE_LOSS_MSE or MAE_LOSS_SMOOTH_L1", who);
+  MAE_REQUIRE(!ready_events || num_ready == e->depth + 1, "%s: need one event slot per gradient-ready point (%d)", who, e->depth + 1);
+  MAE_TRY(check_image_dtype(image_dtype, who));
+  MAE_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)params & 15) == 0 && ((uintptr_t)target_params & 15) == 0, "%s: workspace must be 256-byte aligned, params 16-byte", who);
+  const JepaPlan jp = make_jepa_plan(e, batch, num_context, num_blocks, block_tokens);
+  MAE_REQUIRE(workspace_bytes >= jp.total, "%s: workspace too small (%lld < %lld bytes)", who, (long long)workspace_bytes, (long long)jp.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const int N = e->L - 1;
+  const int64_t Mp = (int64_t)batch * num_blocks * block_tokens;
+  int32_t* ctx32 = reinterpret_cast<int32_t*>(ws + jp.ctx32);
+  int32_t* tgt32 = reinterpret_cast<int32_t*>(ws + jp.tgt32);
+  int32_t* tgt_rows = reinterpret_cast<int32_t*>(ws + jp.tgt_rows);
+  float* h = h_out ? h_out : reinterpret_cast<float*>(ws + jp.h);
+  MAE_TRY(launch_idx_to_i32(idx_context, ctx32, (int64_t)batch * num_context, s));
+  MAE_TRY(launch_idx_to_i32(idx_target, tgt32, Mp, s));
+  // ---- phase A: target encoder over all patch tokens (EMA weights), fp32 output, parameter-free LayerNorm of the target rows
+  {
+    Ctx c{e, target_params, (const char*)target_wcache, nullptr, ws + jp.phase, s, e->act, (int64_t)dtype_size(e->act)};
+    float* xenc = reinterpret_cast<float*>(ws + jp.phase + jp.xenc);
+    MAE_TRY(launch_iota_tokens(c.buf<int32_t>(jp.tgt.keep32), batch, N, s));
+    MAE_TRY(forward_encoder_impl(c, jp.tgt, images, image_dtype, xenc));
+    MAE_TRY(launch_rows_from_tokens(tgt32, batch, num_blocks * block_tokens, N, tgt_rows, s));
+    MAE_TRY(launch_fill(reinterpret_cast<float*>(ws + jp.ones), 1.0f, e->D, s));
+    MAE_HIP(hipMemsetAsync(ws + jp.zeros, 0, (size_t)e->D * 4, s));
+    float* stat = reinterpret_cast<float*>(ws + jp.stat);
+    RUN(TK_LN_FWD, 0, Mp * e->D * 8, launch_layernorm_fwd(xenc, nullptr, nullptr, tgt_rows, reinterpret_cast<float*>(ws + jp.ones), reinterpret_cast<float*>(ws + jp.zeros),
+                                                          1e-5f, Mp, e->D, MAE_F32, h, stat, stat + Mp, s));  // F.layer_norm default eps
+  }
+  if (!grads) return 0;  // targets only
+  // ---- phase B: context encoder, predictor, loss, backward
+  Ctx c{e, params, (const char*)wcache, grads, ws + jp.phase, s, e->act, (int64_t)dtype_size(e->act)};
+  c.ready = ready_events;
+  const Plan& pl = jp.ctx;
+  MAE_HIP(hipMemcpyAsync(c.buf<int32_t>(pl.keep32), ctx32, (size_t)batch * num_context * 4, hipMemcpyDeviceToDevice, s));
+  MAE_TRY(forward_encoder_impl(c, pl, images, image_dtype, nullptr));
+  const JepaSeq seq{ctx32, tgt32, num_blocks};
+  MAE_TRY(forward_decoder_impl(c, pl, pred_out, &seq));
+  const float* pred = pred_out ? pred_out : c.buf<float>(pl.pred);
+  if (loss_kind == MAE_LOSS_SMOOTH_L1)
+    RUN(TK_LOSS, 0, Mp * e->D * (8 + c.as), launch_smooth_l1(pred, h, Mp * e->D, grad_scale, loss_out, c.buf<>(pl.dpred), e->act, c.buf<float>(pl.loss_scratch), s));
+  else
+    RUN(TK_LOSS, 0, Mp * e->D * (8 + c.as), launch_mse(pred, h, Mp * e->D, grad_scale, loss_out, c.buf<>(pl.dpred), e->act, c.buf<float>(pl.loss_scratch), s));
+  return backward_impl(c, pl, nullptr, &seq);
+}
+
+static int optimizer_step_impl(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int64_t step,
+                               float* stats_out, float* scratch, float* ema_target, void* ema_wcache, float ema_momentum, void* stream) {
   MAE_REQUIRE(e && params && grads && exp_avg && exp_avg_sq && stats_out && scratch, "mae_engine_optimizer_step: null argument");
   MAE_REQUIRE(step >= 1, "mae_engine_optimizer_step: step is 1-based");
   MAE_REQUIRE(e->act == MAE_F32 || wcache, "mae_engine_optimizer_step: bf16 engine needs the weight cache");
@@ -818,9 +946,27 @@ extern "C" int mae_engine_optimizer_step(mae_engine_t* e, float* params, float* 
   RUN(TK_OPTIM, 0, n * 4, launch_grad_norm(grads, n, max_norm, stats_out, scratch, s));
   RUN(TK_OPTIM, 0, n * (28 + (e->act == MAE_BF16 ? 2 : 0)),
       launch_adamw(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, stats_out,
-                   e->act == MAE_BF16 ? reinterpret_cast<bf16*>(wcache) : nullptr, s));
+                   e->act == MAE_BF16 ? reinterpret_cast<bf16*>(wcache) : nullptr, s, ema_target,
+                   e->act == MAE_BF16 ? reinterpret_cast<bf16*>(ema_wcache) : nullptr, ema_target ? e->params[e->i_dec_mask].offset : 0, ema_momentum));
   if (e->act == MAE_BF16) RUN(TK_OPTIM, 0, e->trans_elems * 6, refresh_transposed(e, params, wcache, s));
   return 0;
+}
+
+extern "C" int mae_engine_optimizer_step(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,
+                                         float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int64_t step,
+                                         float* stats_out, float* scratch, void* stream) {
+  return optimizer_step_impl(e, params, grads, exp_avg, exp_avg_sq, wcache, lr, beta1, beta2, eps, weight_decay, max_norm, step, stats_out,
+                             scratch, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int mae_engine_optimizer_step_ema(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,
+                                             float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int64_t step,
+                                             float* stats_out, float* scratch, float* target_params, void* target_wcache,
+                                             float ema_momentum, void* stream) {
+  MAE_REQUIRE(target_params && (!e || e->act == MAE_F32 || target_wcache), "mae_engine_optimizer_step_ema: null target arena / weight cache");
+  MAE_REQUIRE(ema_momentum >= 0.f && ema_momentum <= 1.f, "mae_engine_optimizer_step_ema: momentum %g outside [0, 1]", (double)ema_momentum);
+  return optimizer_step_impl(e, params, grads, exp_avg, exp_avg_sq, wcache, lr, beta1, beta2, eps, weight_decay, max_norm, step, stats_out,
+                             scratch, target_params, target_wcache, ema_momentum, stream);
 }
 
 extern "C" int mae_engine_timers_enable(mae_engine_t* e, int32_t on) {

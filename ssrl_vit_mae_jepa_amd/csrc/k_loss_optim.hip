@@ -147,12 +147,15 @@ int launch_grad_norm(const float* g, int64_t n, float max_norm, float* stats, fl
 // ---------------------------------------------------------------------------------------------------
 // AdamW, one pass over p/g/m/v (+ optional bf16 operand copy of the new parameters)
 // ---------------------------------------------------------------------------------------------------
-template <bool WBF>
+// EMA (I-JEPA target encoder, no counterpart in the reference): the first ema_n4 float4 of a second parameter arena follow the
+// updated parameters, tgt = mom * tgt + (1 - mom) * p_new, in the same sweep (+ the bf16 operand copy of the target weights)
+template <bool WBF, bool EMA>
 __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n4, float lr,
                                                     float b1, float b2, float eps, float wd, float inv_bc1,
                                                     float inv_sqrt_bc2, const float* __restrict__ stats,
-                                                    bf16* __restrict__ wbf) {
+                                                    bf16* __restrict__ wbf, float* __restrict__ tgt, bf16* __restrict__ tgt_wbf,
+                                                    int64_t ema_n4, float mom) {
   const float coef = stats ? stats[1] : 1.0f;
   const float decay = 1.0f - lr * wd;
   const float step = lr * inv_bc1;
@@ -172,19 +175,26 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* __restrict__ p, const
     store4(m + i * 4, mm);
     store4(v + i * 4, vv);
     if (WBF) store4(wbf + i * 4, pp);
+    if (EMA && i < ema_n4) {
+      const f32x4 tt = load4(tgt + i * 4) * mom + pp * (1.0f - mom);
+      store4(tgt + i * 4, tt);
+      if (WBF) store4(tgt_wbf + i * 4, tt);
+    }
   }
 }
 
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                 float wd, float bc1, float bc2, const float* stats, bf16* wbf, hipStream_t s) {
+                 float wd, float bc1, float bc2, const float* stats, bf16* wbf, hipStream_t s, float* ema_target,
+                 bf16* ema_wbf, int64_t ema_n, float ema_momentum) {
   MAE_REQUIRE(p && g && m && v && n > 0 && n % 4 == 0, "adamw: need n %% 4 == 0 and non-null buffers");
   MAE_REQUIRE(bc1 > 0.f && bc2 > 0.f, "adamw: bias corrections must be positive (step >= 1)");
   const int grid = (int)std::min<int64_t>(cdiv(n / 4, 256), 256 * 16);
   const float inv_bc1 = 1.0f / bc1, inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
-  if (wbf)
-    hipLaunchKernelGGL((adamw_kernel<true>), dim3(grid), dim3(256), 0, s, p, g, m, v, n / 4, lr, b1, b2, eps, wd, inv_bc1, inv_sqrt_bc2, stats, wbf);
-  else
-    hipLaunchKernelGGL((adamw_kernel<false>), dim3(grid), dim3(256), 0, s, p, g, m, v, n / 4, lr, b1, b2, eps, wd, inv_bc1, inv_sqrt_bc2, stats, wbf);
+  MAE_REQUIRE(!ema_target || (ema_n > 0 && ema_n % 4 == 0 && ema_n <= n && (!wbf || ema_wbf)), "adamw: bad EMA range");
+#define ADAMW(W, E) hipLaunchKernelGGL((adamw_kernel<W, E>), dim3(grid), dim3(256), 0, s, p, g, m, v, n / 4, lr, b1, b2, eps, wd, inv_bc1, inv_sqrt_bc2, stats, wbf, ema_target, ema_wbf, ema_n / 4, ema_momentum)
+  if (wbf) { if (ema_target) ADAMW(true, true); else ADAMW(true, false); }
+  else     { if (ema_target) ADAMW(false, true); else ADAMW(false, false); }
+#undef ADAMW
   MAE_LAUNCH_CHECK();
   return 0;
 }

@@ -35,6 +35,18 @@ int launch_decoder_assemble_bwd(const float* dx, const int32_t* inv, const int32
 // target (B*m, P) fp32 in (py, px, c) order for patch max(mask[b][j]-1, 0)
 int launch_patchify_gather(const float* images, const int32_t* mask32, int B, int m, int C, int img, int p,
                            float* target, hipStream_t s);
+// ---- k_jepa.hip: I-JEPA predictor input / target rows / latent loss (no reference code: spec in DESIGN.md) -----------------
+int launch_iota_tokens(int32_t* keep32, int B, int N, hipStream_t s);                 // keep[b][j] = j + 1
+int launch_fill(float* p, float v, int64_t n, hipStream_t s);
+int launch_build_tail_row_map(int seqs, int T, int m, int32_t* rows, hipStream_t s);  // last m rows of every sequence of T
+int launch_rows_from_tokens(const int32_t* tok, int B, int per_image, int N, int32_t* rows, hipStream_t s);  // b*N + tok-1
+int launch_predictor_assemble(const void* xdec, int dt, const int32_t* ctx32, const int32_t* tgt32, const float* mask_token, const float* pos,
+                              int B, int k, int nblk, int m, int L, int Dd, float* out, hipStream_t s);
+int launch_predictor_assemble_bwd(const float* dx, int B, int k, int nblk, int m, int Dd, int dt, void* d_xdec, float* d_mask_token,
+                                  float* partial, hipStream_t s);
+int launch_smooth_l1(const float* pred, const float* target, int64_t n, float grad_scale, float* loss, void* d_pred, int dpred_dt,
+                     float* scratch, hipStream_t s);
+
 // ---- k_pixels_u8.hip: the same three pixel readers on uint8 images, ToTensor + Normalize(.5,.5) fused into the read -----
 int launch_gather_patches_u8(const uint8_t* images, const int32_t* tok, int B, int k, int C, int img, int p, int dt, void* out, hipStream_t s);
 int launch_mse_from_images_u8(const float* pred, const uint8_t* images, const int32_t* mask32, int B, int m, int C, int img, int p,
@@ -60,8 +72,10 @@ int launch_mse_from_images(const float* pred, const float* images, const int32_t
 // stats[0] = ||g||_2, stats[1] = min(1, max_norm/(norm+1e-6)).  scratch >= 1024+ floats
 int launch_grad_norm(const float* g, int64_t n, float max_norm, float* stats, float* scratch, hipStream_t s);
 // AdamW with g scaled by stats[1]; optionally refresh bf16 copy of the params (wbf may be null)
+// ema_target != null: target[0 .. ema_n) = ema_momentum * target + (1 - ema_momentum) * p_new in the same sweep (+ its bf16 copy)
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                 float wd, float bc1, float bc2, const float* stats, bf16* wbf, hipStream_t s);
+                 float wd, float bc1, float bc2, const float* stats, bf16* wbf, hipStream_t s, float* ema_target = nullptr,
+                 bf16* ema_wbf = nullptr, int64_t ema_n = 0, float ema_momentum = 0.f);
 int launch_f32_to_bf16(const float* src, bf16* dst, int64_t n, hipStream_t s);
 // dst[c][r] = (bf16) src[r][c]
 int launch_transpose_to_bf16(const float* src, bf16* dst, int rows, int cols, hipStream_t s);

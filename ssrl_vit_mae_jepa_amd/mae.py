@@ -233,11 +233,12 @@ class MaskedAutoencoder(nn.Module):
             decoder_embed_dim=int(decoder_cfg.get("decoder_embed_dim", 512)),
             decoder_depth=int(decoder_cfg.get("decoder_depth", 4)),
             decoder_num_heads=int(decoder_cfg.get("decoder_num_heads", 6)),
+            pred_dim=int(general_cfg.get("pred_dim", 0)),  # 0 = pixels (MAE); the I-JEPA net sets the encoder width
         )
         self._dims = cfg
         self._engine = Engine(cfg, precision)
         self.sequence_length = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
-        self.patch_dim = cfg["patch_size"] ** 2 * cfg["in_chans"]
+        self.patch_dim = cfg["pred_dim"] or cfg["patch_size"] ** 2 * cfg["in_chans"]  # width of the prediction head
 
         self.encoder = _Encoder()
         self.decoder = _Decoder()

@@ -44,6 +44,9 @@ class MAEPretrainModule(nn.Module):
         self.hparams = {"model_cfg": model_cfg, "training_cfg": training_cfg}
         self.model = MaskedAutoencoder(
             general_cfg=model_cfg["general"], encoder_cfg=model_cfg["encoder"], decoder_cfg=model_cfg["decoder"])
+        self._init_training_state(training_cfg)
+
+    def _init_training_state(self, training_cfg: Dict[str, Any]) -> None:
         self.mask_start = training_cfg.get("mask_ratio_start", 0.5)
         self.mask_end = training_cfg.get("mask_ratio_end", 0.85)
         self.ramp_epochs = training_cfg.get("mask_ramp_epochs", 200)
@@ -164,6 +167,37 @@ class MAEPretrainModule(nn.Module):
             self._comm_stream = torch.cuda.Stream(device=dev)
         return self._bucket_events, self._comm_stream
 
+    def _exchanged_loss_and_grads(self, compute, process_group=None) -> torch.Tensor:
+        """Run ``compute(grad_scale, ready_events, loss_out)`` (a native loss+grads call) and, with torch.distributed
+        initialised, sum the gradient buckets over the ranks as the backward pass finishes them.  Returns the GLOBAL mean
+        loss as a device scalar (no host sync); afterwards ``model.flat_grads`` holds the reduced gradients."""
+        model = self.model
+        dev = model._require_cuda()
+        dist = torch.distributed
+        world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        if world == 1:
+            return compute(1.0, None, None)
+        n = model.engine.trainable_elems
+        buf = model.grad_buffer
+        loss_slot = buf[n:n + 1]
+        if self.overlap_exchange:
+            events, comm = self._exchange_state(dev)
+            main = torch.cuda.current_stream(dev)
+            comm.wait_stream(main)  # the previous step's optimizer has read the buffer before it is reduced into again
+            compute(1.0 / world, events, loss_slot)
+            works = []
+            with torch.cuda.stream(comm):
+                for j, b, e in self.gradient_buckets():
+                    comm.wait_event(events[j])
+                    works.append(dist.all_reduce(buf[b:e], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
+                for w in works:
+                    w.wait()
+            main.wait_stream(comm)
+        else:  # one blocking collective after the whole backward pass
+            compute(1.0 / world, None, loss_slot)
+            dist.all_reduce(buf[:n + 1], op=dist.ReduceOp.SUM, group=process_group)
+        return loss_slot / world  # sum of the ranks' local means / world = global mean (equal local batches)
+
     def fused_training_step(self, images: torch.Tensor, noise: Optional[torch.Tensor] = None, lr: Optional[float] = None,
                             process_group=None) -> torch.Tensor:
         """One whole pretrain step.  With torch.distributed initialised every rank computes its rows of the global batch
@@ -172,33 +206,10 @@ class MAEPretrainModule(nn.Module):
         the same global-norm clip + AdamW.  Returns the GLOBAL mean loss as a device scalar (no host sync)."""
         model = self.model
         dev = model._require_cuda()
-        dist = torch.distributed
-        world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         if noise is None:
             noise = torch.rand(images.shape[0], model.sequence_length, device=dev)
-        if world == 1:
-            loss = model.loss_and_grads(images, noise)
-        else:
-            n = model.engine.trainable_elems
-            buf = model.grad_buffer
-            loss_slot = buf[n:n + 1]
-            if self.overlap_exchange:
-                events, comm = self._exchange_state(dev)
-                main = torch.cuda.current_stream(dev)
-                comm.wait_stream(main)  # the previous step's optimizer has read the buffer before it is reduced into again
-                model.loss_and_grads(images, noise, grad_scale=1.0 / world, ready_events=events, loss_out=loss_slot)
-                works = []
-                with torch.cuda.stream(comm):
-                    for j, b, e in self.gradient_buckets():
-                        comm.wait_event(events[j])
-                        works.append(dist.all_reduce(buf[b:e], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
-                    for w in works:
-                        w.wait()
-                main.wait_stream(comm)
-            else:  # one blocking collective after the whole backward pass
-                model.loss_and_grads(images, noise, grad_scale=1.0 / world, loss_out=loss_slot)
-                dist.all_reduce(buf[:n + 1], op=dist.ReduceOp.SUM, group=process_group)
-            loss = loss_slot / world  # sum of the ranks' local means / world = global mean (equal local batches)
+        loss = self._exchanged_loss_and_grads(
+            lambda scale, events, out: model.loss_and_grads(images, noise, grad_scale=scale, ready_events=events, loss_out=out), process_group)
         self.optimizer_step(lr)
         self.global_step += 1
         self.log("train_loss", loss)
@@ -209,7 +220,8 @@ class MAEPretrainModule(nn.Module):
         """(index in self.parameters() order, state_dict name, has optimizer state) -- the reference hands every
         parameter to AdamW (src/training/mae.py:62); only those that receive a gradient get state."""
         trainable = set(self.model.named_flat_views(self.model.flat_grads))
-        return [(i, n, n in trainable) for i, (n, _p) in enumerate(self.model.named_parameters())]
+        strip = lambda n: n[4:] if n.startswith("net.") else n  # noqa: E731  (IJEPA keeps its parameter table in .net)
+        return [(i, strip(n), strip(n) in trainable) for i, (n, _p) in enumerate(self.model.named_parameters())]
 
     def optimizer_state_dict(self) -> Dict[str, Any]:
         m, v, _ = self._opt_state()

@@ -1,0 +1,82 @@
+"""I-JEPA host logic on CPU: the multi-block mask sampler against the oracle's plain-loop version (integer-exact), its
+structural properties, and a finite-difference check of the oracle itself.  There is NO reference I-JEPA code (README.md:1,9
+name it only): oracle/jepa_oracle.py is our restatement of DESIGN.md's specification -- parity unpinned by construction."""
+import pytest
+import torch
+
+from oracle import jepa_oracle as J
+from ssrl_vit_mae_jepa_amd import IJEPAPretrainModule, sample_block_masks
+
+
+@pytest.mark.parametrize("cfg", [J.JEPA_MICRO, J.JEPA_VIT_S8, J.JEPA_VIT_L14])
+def test_sampler_equals_the_oracle_loops_and_is_well_formed(cfg):
+    for seed in range(12):
+        B = 3 + 5 * seed
+        ctx_ref, tgt_ref = J.sample_masks(cfg, B, torch.Generator().manual_seed(seed))
+        ctx, tgt = sample_block_masks(B, cfg.grid, torch.Generator().manual_seed(seed), cfg.num_target_blocks, cfg.target_scale,
+                                      cfg.target_aspect, cfg.context_scale)
+        assert ctx.dtype == tgt.dtype == torch.int64 and torch.equal(ctx, ctx_ref) and torch.equal(tgt, tgt_ref)
+        N, g = cfg.num_patches, cfg.grid
+        assert int(ctx.min()) >= 1 and int(ctx.max()) <= N and int(tgt.min()) >= 1 and int(tgt.max()) <= N
+        assert bool((ctx.diff(dim=1) > 0).all())                                   # ascending, no duplicates
+        for b in range(B):
+            taken = set(tgt[b].flatten().tolist())
+            assert not (set(ctx[b].tolist()) & taken)                              # the context never sees a target patch
+            for blk in tgt[b]:                                                     # every target is a full rectangle of the grid
+                rows, cols = (blk - 1) // g, (blk - 1) % g
+                h, w = int(rows.max() - rows.min()) + 1, int(cols.max() - cols.min()) + 1
+                assert h * w == blk.numel() and len(set(blk.tolist())) == blk.numel()
+        frac = tgt.shape[2] / N
+        assert 0.05 < frac < 0.3                                                   # scale (0.15, 0.2) after the aspect rounding
+
+
+def test_block_sizes_follow_scale_and_aspect():
+    assert J.block_size(14, (0.15, 0.2), (0.75, 1.5), 0.0, 0.0) == (5, 6)     # int(196*.15)=29: sqrt(29*.75)=4.66->5, sqrt(29/.75)=6.2->6
+    assert J.block_size(14, (0.85, 1.0), (1.0, 1.0), 1.0, 0.5) == (13, 13)    # a full-size block is clipped to grid - 1
+    assert J.block_size(12, (0.15, 0.2), (0.75, 1.5), 1.0, 1.0) == (6, 4)      # int(144*.2)=28: sqrt(28*1.5)=6.48->6, sqrt(28/1.5)=4.32->4
+
+
+def test_oracle_gradient_matches_finite_differences():
+    cfg = J.JEPAConfig(image_size=16, patch_size=4, embed_dim=16, depth=1, num_heads=1, pred_embed_dim=16, pred_depth=1, pred_num_heads=1)
+    torch.manual_seed(0)
+    p = {k: v.double() for k, v in J.init_params(cfg, 3).items()}
+    for n, t in p.items():
+        if n.endswith(".bias") or "norm" in n or n.endswith("_token"):
+            t.add_(torch.randn(t.shape, dtype=torch.float64) * 0.05)
+    pt = {k: v.clone() + 0.01 * torch.randn_like(v) for k, v in p.items()}
+    images = torch.rand(2, 3, 16, 16, dtype=torch.float64) * 2 - 1
+    ctx = torch.tensor([[1, 2, 5, 6, 9], [3, 4, 7, 8, 16]])
+    tgt = torch.tensor([[[11, 12, 15, 16], [10, 11, 14, 15]], [[1, 2, 5, 6], [9, 10, 13, 14]]])
+    for kind in ("mse", "smooth_l1"):
+        c = J.JEPAConfig(**{**cfg.__dict__, "loss": kind})
+        loss, grads, _ = J.loss_and_grads(p, pt, c, images, ctx, tgt)
+        for name in ("encoder.vit.blocks.0.attn.qkv.weight", "decoder.mask_token", "decoder.decoder_pred.bias", "encoder.vit.patch_embed.proj.weight"):
+            flat = p[name].view(-1)
+            i = int(torch.randint(flat.numel(), (1,)))
+            old = float(flat[i]); eps = 1e-6
+            flat[i] = old + eps; up = float(J.loss_and_grads(p, pt, c, images, ctx, tgt)[0])
+            flat[i] = old - eps; dn = float(J.loss_and_grads(p, pt, c, images, ctx, tgt)[0])
+            flat[i] = old
+            assert abs((up - dn) / (2 * eps) - float(grads[name].view(-1)[i])) < 1e-6 + 1e-5 * abs(float(grads[name].view(-1)[i])), (kind, name)
+    # the target encoder receives no gradient and the unused class token none either
+    assert "encoder.vit.cls_token" not in grads and "encoder.mask_token" not in grads
+
+
+def test_module_schedules_and_state_layout():
+    m = IJEPAPretrainModule(dict(general=dict(image_size=32, patch_size=4), encoder=dict(embed_dim=48, depth=2, num_heads=2),
+                                 predictor=dict(pred_embed_dim=32, pred_depth=1, pred_num_heads=2)),
+                            dict(total_epochs=10, steps_per_epoch=100, ema_start=0.996, ema_end=1.0, batch_size=512))
+    assert m.ema_momentum() == 0.996 and m.gradient_clip_val == float("inf")
+    m.global_step = 500
+    assert abs(m.ema_momentum() - J.ema_momentum_at(500, 1000)) < 1e-12 and abs(m.ema_momentum() - 0.998) < 1e-12
+    m.global_step = 5000
+    assert m.ema_momentum() == 1.0
+    sd = m.model.state_dict()
+    assert "target_arena" in sd and "net.decoder.decoder_pred.weight" in sd and sd["net.decoder.decoder_pred.weight"].shape == (48, 32)
+    assert torch.equal(sd["target_arena"], m.model.net.flat_params)               # the target starts as a copy of the context encoder
+    tsd = m.model.target_state_dict()
+    assert "encoder.vit.blocks.1.mlp.fc2.weight" in tsd and all(k.startswith("encoder.vit.") for k in tsd)
+    opt = m.optimizer_state_dict()
+    assert opt["param_groups"][0]["params"] == list(range(len(list(m.model.parameters()))))
+    # hand sum: context enc(36) 1.5580 + predictor 1.5047 GF forward, x3; target enc(144) 6.5186 GF forward only
+    assert abs(J.flops_per_image_step(J.JEPA_VIT_S8, 36, 30) / 1e9 - 15.707) < 0.005
