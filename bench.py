@@ -51,6 +51,19 @@ def flops_per_image_step(general=GENERAL, encoder=ENCODER, decoder=DECODER) -> f
     return 3.0 * fwd
 
 
+def jepa_flops_per_image_step(general, encoder, predictor, k: float, m: int) -> float:
+    """I-JEPA: context encoder (k tokens) and predictor (nblk sequences of k + m tokens) forward + backward = 3 x forward,
+    target encoder (all N patches, no gradient) 1 x forward; 2*MAC, GEMMs + attention matmuls."""
+    N = (general["image_size"] // general["patch_size"]) ** 2
+    P = general["patch_size"] ** 2 * general.get("in_chans", 3)
+    D, depth, Dp, dp = encoder["embed_dim"], encoder["depth"], predictor["pred_embed_dim"], predictor["pred_depth"]
+    nb = int(general.get("num_target_blocks", 4))
+    enc = lambda t: 2 * t * P * D + depth * t * 24 * D * D + depth * 4 * t * t * D  # noqa: E731
+    T = k + m
+    pred = 2 * k * D * Dp + nb * (dp * T * 24 * Dp * Dp + dp * 4 * T * T * Dp + 2 * m * Dp * D)
+    return 3.0 * (enc(k) + pred) + enc(N)
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     tools/pmc_traffic.py); PMC counters cannot be read from inside the timed process, so this is the profiled value."""
@@ -101,6 +114,28 @@ def cpu_baseline(general, encoder, decoder, label: str, batch: int = 64, steps: 
                       f"{max(1, steps - 1)} ('medium', the reference's literal setting), median"}
 
 
+def jepa_cpu_baseline(general, encoder, predictor, label: str, batch: int = 32, steps: int = 2) -> dict:
+    """The I-JEPA oracle (our CPU restatement of DESIGN.md's specification; the reference has no I-JEPA code) timed on the host cores."""
+    from oracle import jepa_oracle as J
+    cfg = J.JEPAConfig(image_size=general["image_size"], patch_size=general["patch_size"], in_chans=general.get("in_chans", 3),
+                       embed_dim=encoder["embed_dim"], depth=encoder["depth"], num_heads=encoder["num_heads"],
+                       pred_embed_dim=predictor["pred_embed_dim"], pred_depth=predictor["pred_depth"], pred_num_heads=predictor["pred_num_heads"],
+                       loss=general.get("loss", "mse"))
+    torch.set_float32_matmul_precision("highest")
+    p = J.init_params(cfg, 73)
+    pt = {k: v.clone() for k, v in p.items()}
+    state, times = {}, []
+    images = J.M.synthetic_images(batch, cfg.as_mae())
+    for step in range(1, steps + 2):
+        ctx, tgt = J.sample_masks(cfg, batch, torch.Generator().manual_seed(step))
+        t0 = time.perf_counter()
+        J.train_step(p, pt, cfg, state, images, ctx, tgt, 1e-4, step, 0.996)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": batch / t, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"oracle.jepa train_step fp32 'highest', {label}, batch {batch}, 1 warm-up + {steps} timed steps, median"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,30 +168,52 @@ def main() -> None:
 
     from ssrl_vit_mae_jepa_amd import MAEPretrainModule
     general, encoder, decoder, train = GENERAL, ENCODER, DECODER, TRAIN
+    predictor = None
     if args.config:
         import yaml
         y = yaml.safe_load(open(args.config))
-        general = dict(mask_ratio=float(y["pretrain"].get("mask_ratio_end", 0.75)), engine_precision="bf16", **y["model"]["general"])
-        encoder, decoder = y["model"]["encoder"], y["model"]["decoder"]
-        train = dict(y["pretrain"], mask_ratio_start=general["mask_ratio"], mask_ratio_end=general["mask_ratio"])
+        predictor = y["model"].get("predictor")   # an I-JEPA config (configs/ijepa_*.yaml)
+        encoder = y["model"]["encoder"]
+        if predictor:
+            general = dict(engine_precision="bf16", **y["model"]["general"])
+            decoder, train = None, dict(y["pretrain"])
+        else:
+            general = dict(mask_ratio=float(y["pretrain"].get("mask_ratio_end", 0.75)), engine_precision="bf16", **y["model"]["general"])
+            decoder = y["model"]["decoder"]
+            train = dict(y["pretrain"], mask_ratio_start=general["mask_ratio"], mask_ratio_end=general["mask_ratio"])
     B = args.batch if args.batch else (2000 if not args.config else max(1, int(train["batch_size"]) // 8))
     img, chans = int(general["image_size"]), int(general.get("in_chans", 3))
-    label = (f"ViT {encoder['embed_dim']}x{encoder['depth']}x{encoder['num_heads']}h /{general['patch_size']} {img}px MAE, dec "
-             f"{decoder['decoder_embed_dim']}x{decoder['decoder_depth']}x{decoder['decoder_num_heads']}h")
+    if predictor:
+        label = (f"ViT {encoder['embed_dim']}x{encoder['depth']}x{encoder['num_heads']}h /{general['patch_size']} {img}px I-JEPA (no reference code), "
+                 f"predictor {predictor['pred_embed_dim']}x{predictor['pred_depth']}x{predictor['pred_num_heads']}h, latent {general.get('loss', 'mse')}")
+    else:
+        label = (f"ViT {encoder['embed_dim']}x{encoder['depth']}x{encoder['num_heads']}h /{general['patch_size']} {img}px MAE, dec "
+                 f"{decoder['decoder_embed_dim']}x{decoder['decoder_depth']}x{decoder['decoder_num_heads']}h")
     if not args.config:
         label = "ViT-S/8 96px MAE (enc 384x12x6h, dec 192x2x6h, mask_ratio 0.75)"
     tcfg = dict(train, batch_size=B * world)
     torch.manual_seed(73)
-    module = MAEPretrainModule(dict(general=general, encoder=encoder, decoder=decoder), tcfg).to(dev)
+    if predictor:
+        from ssrl_vit_mae_jepa_amd import IJEPAPretrainModule
+        module = IJEPAPretrainModule(dict(general=general, encoder=encoder, predictor=predictor), tcfg).to(dev)
+    else:
+        module = MAEPretrainModule(dict(general=general, encoder=encoder, decoder=decoder), tcfg).to(dev)
     module.on_train_epoch_start()
     model = module.model
-    L = model.sequence_length
+    L = (img // int(general["patch_size"])) ** 2 + 1
 
     # synthetic inputs, resident in HBM before the timed region; every rank draws the global tensors and keeps its rows
     g = torch.Generator(device=dev).manual_seed(73)
     images = (torch.rand(B * world, chans, img, img, device=dev, generator=g) * 2 - 1)[rank * B:(rank + 1) * B].contiguous()
     total = args.warmup + args.steps
-    noises = [torch.rand(B * world, L, device=dev, generator=g)[rank * B:(rank + 1) * B].contiguous() for _ in range(total)]
+    if predictor:  # per-step multi-block masks of the GLOBAL batch (host sampler, seeded), this rank's rows, uploaded before timing
+        mg = torch.Generator().manual_seed(73)
+        masks = [model.sample_masks(B * world, mg) for _ in range(total)]
+        noises = [(c[rank * B:(rank + 1) * B].to(dev), t[rank * B:(rank + 1) * B].to(dev)) for c, t in masks]
+        step_fn = lambda i: module.fused_training_step(images, noises[i][0], noises[i][1])  # noqa: E731
+    else:
+        noises = [torch.rand(B * world, L, device=dev, generator=g)[rank * B:(rank + 1) * B].contiguous() for _ in range(total)]
+        step_fn = lambda i: module.fused_training_step(images, noises[i])  # noqa: E731
 
     def sync():
         if world > 1:
@@ -164,7 +221,7 @@ def main() -> None:
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
-        module.fused_training_step(images, noises[i])
+        step_fn(i)
     sync()
     # one event per step on the launch stream (torch's current stream IS the engine's launch stream): p10/p50/p90
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -172,7 +229,7 @@ def main() -> None:
     loss = None
     marks[0].record()
     for i in range(args.steps):
-        loss = module.fused_training_step(images, noises[args.warmup + i])
+        loss = step_fn(args.warmup + i)
         marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
@@ -192,14 +249,18 @@ def main() -> None:
         model.engine.timers_enable(True)
         t1 = time.perf_counter()
         for i in range(args.steps):
-            module.fused_training_step(images, noises[args.warmup + i])
+            step_fn(args.warmup + i)
         sync()
         timed_ms = 1e3 * (time.perf_counter() - t1) / args.steps
         model.engine.timers_enable(False)
         kernels = model.engine.timers_read()
     if rank == 0:
         img_s = B * world * args.steps / elapsed
-        fl = flops_per_image_step(general, encoder, decoder)
+        if predictor:
+            ks = [noises[args.warmup + i][0].shape[1] for i in range(args.steps)]
+            fl = jepa_flops_per_image_step(general, encoder, predictor, sum(ks) / len(ks), noises[args.warmup][1].shape[2])
+        else:
+            fl = flops_per_image_step(general, encoder, decoder)
         out = {
             # BASELINE.json's metric, verbatim, for the default workload; a --config run names its own model
             "metric": ("images/sec pretrain step (fwd+bwd+opt), ViT-S/8 96px MAE, 1/2/4/8 MI355X" if not args.config
@@ -230,7 +291,8 @@ def main() -> None:
                                   "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                               for n, v in kernels.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(general, encoder, decoder, label, batch=64 if img <= 96 else 8)
+            out["cpu_baseline"] = (jepa_cpu_baseline(general, encoder, predictor, label, batch=32 if img <= 96 else 4) if predictor
+                                   else cpu_baseline(general, encoder, decoder, label, batch=64 if img <= 96 else 8))
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -176,13 +176,17 @@ class IJEPA(nn.Module):
         B = images.shape[0]
         if idx_context.dim() != 2 or idx_target.dim() != 3 or idx_context.shape[0] != B or idx_target.shape[0] != B:
             raise ValueError(f"idx_context must be (B, k) and idx_target (B, nblk, m); got {tuple(idx_context.shape)}, {tuple(idx_target.shape)}")
-        idx_context = idx_context.to(device=dev, dtype=torch.int64).contiguous()
-        idx_target = idx_target.to(device=dev, dtype=torch.int64).contiguous()
-        lo = min(int(idx_context.min()), int(idx_target.min()))
-        hi = max(int(idx_context.max()), int(idx_target.max()))
-        if lo < 1 or hi > self.num_patches:
-            raise IndexError(f"I-JEPA token ids must be patch tokens 1..{self.num_patches} (got {lo}..{hi})")
-        return idx_context, idx_target
+        out = []
+        for idx in (idx_context, idx_target):
+            if idx.is_cuda:  # already on the device: no host round trip in the step; ids are clamped into the patch range
+                idx = idx.to(device=dev, dtype=torch.int64).clamp(1, self.num_patches).contiguous()
+            else:            # host tensors (what sample_block_masks returns): strict check, then upload
+                lo, hi = int(idx.min()), int(idx.max())
+                if lo < 1 or hi > self.num_patches:
+                    raise IndexError(f"I-JEPA token ids must be patch tokens 1..{self.num_patches} (got {lo}..{hi})")
+                idx = idx.to(device=dev, dtype=torch.int64, non_blocking=True).contiguous()
+            out.append(idx)
+        return out[0], out[1]
 
     # ---- the step's native call ----------------------------------------------------------------------------------------------
     def loss_and_grads(self, images: torch.Tensor, idx_context: torch.Tensor, idx_target: torch.Tensor, grad_scale: float = 1.0,

