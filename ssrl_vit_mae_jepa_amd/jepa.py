@@ -163,8 +163,11 @@ class IJEPA(nn.Module):
             raise ValueError(f"bad I-JEPA token counts (batch {B}, context {k}, {nblk} blocks of {m})")
         dev = self._require_cuda()
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            # the context length changes from step to step (batch minimum of the sampled masks): grow with headroom so that
+            # a slightly longer context a few steps later does not reallocate again
+            grown = self._workspace is not None
             self._workspace = None
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._workspace = torch.empty(int(need * 1.25) if grown else need, dtype=torch.uint8, device=dev)
         return self._workspace
 
     # ---- masks ---------------------------------------------------------------------------------------------------------------
