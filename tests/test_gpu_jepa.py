@@ -153,6 +153,22 @@ def test_full_size_properties_vits8_b2000(dev):
     assert torch.equal(la, lb) and torch.equal(gu, model.flat_grads)
 
 
+@pytest.mark.parametrize("prec,tol_loss,tol_grad", [("fp32", 1e-4, 3e-4), ("bf16", 5e-3, 5e-2)])
+def test_vitl14_geometry_matches_oracle(dev, prec, tol_loss, tol_grad):
+    """BASELINE.json configs[4] shapes (ViT-L/14 224 px: 256 patches of 14 x 14, width 1024, 16 heads of 64; predictor 384 wide,
+    12 heads of 32) with the depths cut to 2 + 1 so that the CPU oracle finishes in seconds."""
+    cfg = J.JEPAConfig(**{**J.JEPA_VIT_L14.__dict__, "depth": 2, "pred_depth": 1})
+    B = 2
+    model, params, target = build(cfg, prec, dev)
+    images = J.M.synthetic_images(B, cfg.as_mae())
+    ctx, tgt = model.sample_masks(B, torch.Generator().manual_seed(3))
+    loss_ref, grads_ref, aux = J.loss_and_grads(params, target, cfg, images, ctx, tgt, bf16=(prec == "bf16"))
+    l, h, pred = model.loss_and_grads(images.to(dev), ctx, tgt, return_aux=True)
+    assert h.shape == (B, 4, tgt.shape[2], 1024) and rel_err(h, aux["h"]) < (1e-4 if prec == "fp32" else 2e-2)
+    assert abs(l.item() - loss_ref.item()) <= tol_loss * abs(loss_ref.item())
+    assert grads_close(model, grads_ref, tol_grad)
+
+
 def test_error_behaviour(dev):
     model, _, _ = build(J.JEPA_MICRO, "fp32", dev)
     images = torch.zeros(2, 3, 32, 32, device=dev)
