@@ -64,14 +64,52 @@ def jepa_flops_per_image_step(general, encoder, predictor, k: float, m: int) -> 
     return 3.0 * (enc(k) + pred) + enc(N)
 
 
+PMC_FILE = ROOT / "profiles" / "r02_pmc_hbm_traffic_per_launch.json"
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     tools/pmc_traffic.py); PMC counters cannot be read from inside the timed process, so this is the profiled value."""
-    f = ROOT / "profiles" / "r01_pmc_hbm_traffic_per_launch.json"
     try:
-        return json.loads(f.read_text())[kernel]["hbm_bytes_per_launch"]
+        return json.loads(PMC_FILE.read_text())[kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
+
+
+def hbm_budget(general, encoder, decoder, B: int) -> dict:
+    """Algorithmic HBM bytes of one step under the precision policy (bf16 branch tensors, fp32 residual stream / statistics /
+    gradients / optimizer state; every tensor written once and read by each consumer once), by tensor class, next to the
+    measured PMC sum of the committed profile (default workload only).  Bytes per element of a (rows x width) block tensor:
+      forward 72 = LN1 12 (x 4 + branch 2 -> x 4 + ln 2) + qkv 2+6 + attention 6+2 + proj 2+2 + LN2 12 + fc1 2+16 + fc2 8+2
+      backward 120 = fc2 wgrad 10 + fc2 dgrad*slope 18 + fc1 wgrad 10 + fc1 dgrad 10 + LN2 16 + proj wgrad/dgrad 4+4
+                     + attention 16 + qkv wgrad/dgrad 8+8 + LN1 16"""
+    N = (general["image_size"] // general["patch_size"]) ** 2
+    L, C, img = N + 1, general.get("in_chans", 3), general["image_size"]
+    P = general["patch_size"] ** 2 * C
+    k = max(1, int(L * (1 - general.get("mask_ratio", 0.75))))
+    m = L - k
+    D, depth, Dd, dd = encoder["embed_dim"], encoder["depth"], decoder["decoder_embed_dim"], decoder["decoder_depth"]
+    Ue, Ud, Up = B * k * D, B * L * Dd, B * m
+    per = {"mlp_hidden (act + slope + d_hidden)": 64, "layernorm passes over the fp32 residual (+ bf16 in/out)": 56, "qkv / d_qkv": 36,
+           "attention out / proj / fc2 operands": 36}
+    blocks = depth * Ue + dd * Ud
+    by = {name: v * blocks for name, v in per.items()}
+    n_train = (P * D + 2 * D) + depth * (12 * D * D + 13 * D) + 2 * D + Dd + D * Dd + Dd + dd * (12 * Dd * Dd + 13 * Dd) + 2 * Dd + P * Dd + P
+    by["pixels, patch rows, token assembly, prediction head, loss"] = (
+        2 * B * C * img * img * 4 + B * k * P * 2 * 3 + Ue * (4 + 12) * 2 + Ue * 6 + B * k * Dd * 2 * 2 + Ud * 4 * 2 + B * k * D * 2 * 3
+        + Up * Dd * (2 + 16 + 2 * 3) + Up * P * (4 + 4 + 2 * 3))
+    by["weights, gradients, AdamW state, operand copies"] = n_train * (4 + 4 + 30 + 6)  # wgrad write, norm read, AdamW sweep, transposed copy
+    total = sum(by.values())
+    out = {"algorithmic_bytes_per_step": total, "by_tensor_class": by, "hbm_floor_ms_at_5.5TBps": total / 5.5e12 * 1e3}
+    try:
+        pm = json.loads(PMC_FILE.read_text())
+        if "_step" in pm:
+            out["measured_pmc_bytes_per_step"] = pm["_step"]["hbm_bytes_per_step"]
+            out["measured_over_algorithmic"] = pm["_step"]["hbm_bytes_per_step"] / total
+            out["measured_on"] = pm["_step"].get("workload")
+    except Exception:
+        pass
+    return out
 
 
 def cpu_model() -> str:
@@ -290,6 +328,8 @@ def main() -> None:
                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 and v["flops"] > 0 else None,
                                   "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                               for n, v in kernels.items()}
+        if not predictor:
+            out["hbm_budget"] = hbm_budget(general, encoder, decoder, B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = (jepa_cpu_baseline(general, encoder, predictor, label, batch=32 if img <= 96 else 4) if predictor
                                    else cpu_baseline(general, encoder, decoder, label, batch=64 if img <= 96 else 8))

@@ -26,6 +26,13 @@ for k in sorted(set(fetch) | set(write)):
     rd = 2 * 1024 * fetch[k][0] / max(1, fetch[k][1])
     wr = 1024 * write[k][0] / max(1, write[k][1])
     out[k] = {"launches": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
+# whole-step sum: every launch of every kernel in the profiled run / the number of steps it ran (argv[4], default 3 = 1 warm-up + 2)
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+step_bytes = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in out.values()) / steps
+out["_step"] = {"hbm_bytes_per_step": step_bytes, "steps_in_profile": steps,
+                "workload": sys.argv[5] if len(sys.argv) > 5 else "bench.py default (ViT-S/8 96px MAE, batch 2000)"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(f"HBM bytes per step (all kernels): {step_bytes / 1e9:.1f} GB")
+out.pop("_step")
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:12]:
     print(f"{k:32s} launches {v['launches']:5d}  read {v['hbm_read_bytes_per_launch'] / 1e6:8.1f} MB  write {v['hbm_write_bytes_per_launch'] / 1e6:8.1f} MB")
