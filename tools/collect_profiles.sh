@@ -10,6 +10,6 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers > $OUT/pmc_fetch.log 2>&1
 timeout -k 10 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timers > $OUT/pmc_write.log 2>&1
 cd $ROOT
-python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_hbm_traffic_per_launch.json > $OUT/pmc_traffic.txt
+python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_hbm_traffic_per_launch.json 3 > $OUT/pmc_traffic.txt
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/pmc_fetch/*/*kernel_trace.csv $OUT/pmc_write/*/*kernel_trace.csv
