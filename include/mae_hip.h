@@ -257,7 +257,9 @@ enum {
   MAE_EPI_DGELU = 3,  /* out = acc * gelu_erf'(aux[m][n])  (aux = saved pre-act)  */
   MAE_EPI_GELU_GRAD = 4, /* v = acc+bias rounded to the output type; out = gelu_erf'(v), out2 = gelu_erf(v): the forward
                             saves the derivative instead of the pre-activation, so backward only multiplies  */
-  MAE_EPI_MUL   = 5   /* out = acc * aux[m][n]                                  */
+  MAE_EPI_MUL   = 5,  /* out = acc * aux[m][n]                                  */
+  MAE_EPI_GELU_ACT = 6 /* out = gelu_erf(acc+bias rounded to the output type): one output, for forward-only passes
+                          (the I-JEPA target encoder never runs backward, so nothing but the activation is needed) */
 };
 /* out[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) -- torch.nn.functional.linear.  A, W in `dtype`;
  * out/out2/aux in out_dtype (MAE_EPI_RESID: out and resid fp32). */

@@ -17,7 +17,7 @@ LIB_PATH = Path(os.environ.get("MAE_HIP_LIB") or _HERE / "lib" / "libmae_hip.so"
 MAE_F32, MAE_BF16, MAE_U8 = 0, 1, 2
 PARAM_TRAINABLE, PARAM_FROZEN, PARAM_UNUSED, PARAM_MATRIX = 1, 2, 4, 8
 LOSS_MSE, LOSS_SMOOTH_L1 = 0, 1
-EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL, EPI_GELU_ACT = 0, 1, 2, 3, 4, 5, 6
 ABI_VERSION = 2
 
 

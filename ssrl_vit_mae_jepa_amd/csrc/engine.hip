@@ -273,6 +273,7 @@ struct Ctx {
   int act;
   int64_t as;
   void* const* ready = nullptr;  // hipEvent_t per gradient-ready point (entries may be null), or null
+  bool fwd_only = false;         // no backward will follow (I-JEPA target encoder): the MLP saves no derivative
   const float* P(int i) const { return params + e->params[i].offset; }
   float* Gp(int i) const { return grads + e->params[i].offset; }
   // GEMM operand view of weight i: (out, in) row-major in the activation dtype
@@ -358,7 +359,10 @@ static int block_forward(const Ctx& c, const Plan& pl, const BlockRefs& r, const
   RUN(TK_ATTN_FWD, 4.0 * Bn * heads * (double)T * T * hd, M * 4 * d * c.as, launch_attention_fwd(c.buf<>(b.qkv), Bn, T, heads, hd, c.act, c.buf<>(b.att), c.buf<float>(b.lse), s));
   MAE_TRY(linear(c, c.buf<>(b.att), r.proj_w, r.proj_b, M, d, d, MAE_EPI_NONE, c.act, c.buf<>(pl.branch_a), nullptr, nullptr));
   RUN(TK_LN_FWD, 0, M * d * (8 + 2 * c.as), launch_layernorm_fwd(c.buf<float>(x_in), c.buf<>(pl.branch_a), c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.P(r.ln2_b), eps, M, d, c.act, c.buf<>(b.ln2), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), s));
-  MAE_TRY(linear(c, c.buf<>(b.ln2), r.fc1_w, r.fc1_b, M, hid, d, MAE_EPI_GELU_GRAD, c.act, c.buf<>(b.fc1_pre), c.buf<>(b.fc1_act), nullptr));  // fc1_pre holds gelu'(pre)
+  if (c.fwd_only)
+    MAE_TRY(linear(c, c.buf<>(b.ln2), r.fc1_w, r.fc1_b, M, hid, d, MAE_EPI_GELU_ACT, c.act, c.buf<>(b.fc1_act), nullptr, nullptr));
+  else
+    MAE_TRY(linear(c, c.buf<>(b.ln2), r.fc1_w, r.fc1_b, M, hid, d, MAE_EPI_GELU_GRAD, c.act, c.buf<>(b.fc1_pre), c.buf<>(b.fc1_act), nullptr));  // fc1_pre holds gelu'(pre)
   MAE_TRY(linear(c, c.buf<>(b.fc1_act), r.fc2_w, r.fc2_b, M, d, hid, MAE_EPI_NONE, c.act, c.buf<>(pl.branch_b), nullptr, nullptr));
   return 0;
 }
@@ -906,6 +910,7 @@ extern "C" int mae_engine_jepa_loss_and_grads(mae_engine_t* e, const float* para
   // ---- phase A: target encoder over all patch tokens (EMA weights), fp32 output, parameter-free LayerNorm of the target rows
   {
     Ctx c{e, target_params, (const char*)target_wcache, nullptr, ws + jp.phase, s, e->act, (int64_t)dtype_size(e->act)};
+    c.fwd_only = true;
     float* xenc = reinterpret_cast<float*>(ws + jp.phase + jp.xenc);
     MAE_TRY(launch_iota_tokens(c.buf<int32_t>(jp.tgt.keep32), batch, N, s));
     MAE_TRY(forward_encoder_impl(c, jp.tgt, images, image_dtype, xenc));

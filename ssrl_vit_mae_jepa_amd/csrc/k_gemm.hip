@@ -37,6 +37,8 @@ struct EpiDev {
       const float pre = to_f(from_f<TO>(acc));
       out[o] = from_f<TO>(gelu_erf_grad(pre));
       out2[o] = from_f<TO>(gelu_erf(pre));
+    } else if (mode == MAE_EPI_GELU_ACT) {
+      out[o] = from_f<TO>(gelu_erf(to_f(from_f<TO>(acc))));
     } else {  // MAE_EPI_MUL
       out[o] = from_f<TO>(acc * to_f(reinterpret_cast<const TO*>(aux)[o]));
     }
@@ -113,7 +115,7 @@ static int run_generic(const void* A, int64_t sam, int64_t sak, const void* Bm, 
 
 static int check_epi(const Epi& e, int dt, const char* who) {
   MAE_REQUIRE(e.out, "%s: null output", who);
-  MAE_REQUIRE(e.mode >= MAE_EPI_NONE && e.mode <= MAE_EPI_MUL, "%s: unknown epilogue %d", who, e.mode);
+  MAE_REQUIRE(e.mode >= MAE_EPI_NONE && e.mode <= MAE_EPI_GELU_ACT, "%s: unknown epilogue %d", who, e.mode);
   MAE_REQUIRE((e.mode != MAE_EPI_GELU && e.mode != MAE_EPI_GELU_GRAD) || e.out2, "%s: GELU epilogue needs out2", who);
   MAE_REQUIRE((e.mode != MAE_EPI_RESID && e.mode != MAE_EPI_DGELU && e.mode != MAE_EPI_MUL) || e.aux, "%s: epilogue needs aux", who);
   MAE_REQUIRE(e.mode != MAE_EPI_RESID || e.out_dt == MAE_F32, "%s: RESID epilogue writes fp32", who);

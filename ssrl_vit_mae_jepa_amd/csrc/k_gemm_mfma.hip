@@ -191,6 +191,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const bf16* __restrict_
         }
         store8(reinterpret_cast<TO*>(ep.out) + o, g0, g1);
         store8(reinterpret_cast<TO*>(ep.out2) + o, a0, a1);
+      } else if (MODE == MAE_EPI_GELU_ACT) {
+        f32x4 a0, a1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a0[r] = gelu_fast(to_f(from_f<TO>(v0[r])));
+          a1[r] = gelu_fast(to_f(from_f<TO>(v1[r])));
+        }
+        store8(reinterpret_cast<TO*>(ep.out) + o, a0, a1);
       } else {  // MAE_EPI_MUL
         f32x4 p0, p1;
         load8(reinterpret_cast<const TO*>(ep.aux) + o, p0, p1);
@@ -234,6 +242,7 @@ int mfma_linear_fwd(const bf16* A, const bf16* W, int64_t M, int N, int K, const
     case MAE_EPI_DGELU: return f32out ? launch_nt_ni<MAE_EPI_DGELU, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_DGELU, bf16>(A, W, M, N, K, e, s);
     case MAE_EPI_GELU_GRAD: return f32out ? launch_nt_ni<MAE_EPI_GELU_GRAD, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_GELU_GRAD, bf16>(A, W, M, N, K, e, s);
     case MAE_EPI_MUL: return f32out ? launch_nt_ni<MAE_EPI_MUL, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_MUL, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_GELU_ACT: return f32out ? launch_nt_ni<MAE_EPI_GELU_ACT, float>(A, W, M, N, K, e, s) : launch_nt_ni<MAE_EPI_GELU_ACT, bf16>(A, W, M, N, K, e, s);
     default: return MFMA_UNSUPPORTED;
   }
 }

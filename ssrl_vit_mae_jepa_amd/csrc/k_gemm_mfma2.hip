@@ -319,6 +319,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
               st8(out + o, g0, g1);
               st8(out2 + o, a0, a1);
 #endif
+            } else if (MODE == MAE_EPI_GELU_ACT) {
+              f32x4 a0, a1, g_;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v0[r] = to_f(from_f<TO>(v0[r]));
+                v1[r] = to_f(from_f<TO>(v1[r]));
+              }
+              gelu_fast_pair(v0, a0, g_);
+              gelu_fast_pair(v1, a1, g_);
+              st8(out + o, a0, a1);
             } else if (MODE == MAE_EPI_MUL) {
               f32x4 q0, q1;
               if (PREF) unpack8(qa[PREF ? j : 0][PREF ? mi : 0], q0, q1);
@@ -391,6 +401,7 @@ int mfma_linear_fwd_v2(const bf16* A, const bf16* W, int64_t M, int N, int K, co
     case MAE_EPI_DGELU: return f32out ? launch_nt2_ni<MAE_EPI_DGELU, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_DGELU, bf16>(A, W, M, N, K, e, s);
     case MAE_EPI_GELU_GRAD: return f32out ? launch_nt2_ni<MAE_EPI_GELU_GRAD, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_GELU_GRAD, bf16>(A, W, M, N, K, e, s);
     case MAE_EPI_MUL: return f32out ? launch_nt2_ni<MAE_EPI_MUL, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_MUL, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_GELU_ACT: return f32out ? launch_nt2_ni<MAE_EPI_GELU_ACT, float>(A, W, M, N, K, e, s) : launch_nt2_ni<MAE_EPI_GELU_ACT, bf16>(A, W, M, N, K, e, s);
     default: return MFMA_UNSUPPORTED;
   }
 }

@@ -173,7 +173,7 @@ LIN_SHAPES = [(70, 144, 192), (72, 432, 144), (300, 576, 144), (145, 192, 768), 
 
 @pytest.mark.parametrize("M,N,K", LIN_SHAPES)
 @pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("epi", ["none", "gelu", "resid", "dgelu", "none_f32out", "gelu_grad", "mul"])
+@pytest.mark.parametrize("epi", ["none", "gelu", "resid", "dgelu", "none_f32out", "gelu_grad", "mul", "gelu_act"])
 def test_linear_fwd(dev, M, N, K, dt, epi):
     if dt == F32 and epi == "none_f32out":
         pytest.skip("same as none")
@@ -185,7 +185,7 @@ def test_linear_fwd(dev, M, N, K, dt, epi):
     out = torch.full((M, N), float("nan"), dtype=TDT[odt], device=dev)
     out2 = torch.full((M, N), float("nan"), dtype=TDT[odt], device=dev)
     aux = None
-    mode = {"none": 0, "none_f32out": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5}[epi]
+    mode = {"none": 0, "none_f32out": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5, "gelu_act": 6}[epi]
     if epi == "resid":
         aux = torch.randn(M, N, generator=g)
         ref = aux.double() + acc + bias.double()
@@ -197,6 +197,8 @@ def test_linear_fwd(dev, M, N, K, dt, epi):
         ref = (acc + bias.double()) * aux.double()
     elif epi == "gelu_grad":
         ref = _gelu_grad((acc + bias.double()).to(TDT[odt]).double())
+    elif epi == "gelu_act":  # value only (forward-only passes): gelu of the pre-activation as it would have been stored
+        ref = F.gelu((acc + bias.double()).to(TDT[odt]).double())
     else:
         ref = acc + bias.double()
     check(lib.mae_linear_fwd(_ptr(dv(A)), _ptr(dv(W)), _ptr(dv(bias)), M, N, K, dt, mode, odt, _ptr(out),
@@ -291,7 +293,7 @@ sys.path.insert(0, %r)
 from tests.util import BF16, F32, TDT, check, lib, stream, _ptr
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(11)
-MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5}
+MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5, "gelu_act": 6}
 out = {}
 # (M, N, K): full tiles, a ragged last tile, several tiles per CU, nk = 3 / 6 / 24, N multiples of 192 and of 128
 for M, N, K in [(70000, 1536, 384), (4099, 384, 192), (33000, 1152, 384), (9000, 384, 1536), (20000, 512, 256), (300, 192, 192)]:

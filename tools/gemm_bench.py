@@ -20,6 +20,7 @@ SHAPES = [  # name, M, N, K, epilogue, out dtype
     ("enc fc2 dgrad (dgelu)", 72000, 1536, 384, "dgelu", BF16),
     ("enc fc1 fwd (gelu_grad)", 72000, 1536, 384, "gelu_grad", BF16),
     ("enc fc2 dgrad (mul)", 72000, 1536, 384, "mul", BF16),
+    ("tgt fc1 fwd (gelu_act)", 288000, 1536, 384, "gelu_act", BF16),
     ("enc qkv dgrad", 72000, 384, 1152, "none", BF16),
     ("enc proj fwd resid", 72000, 384, 384, "resid", F32),
     ("dec qkv fwd", 290000, 576, 192, "none", BF16),
@@ -39,7 +40,7 @@ WGRAD_SHAPES = [  # name, M, N, K   (dW[N,K] = dY[M,N]^T A[M,K], db = colsum dY)
     ("dec fc1 wgrad", 290000, 768, 192), ("dec fc2 wgrad", 290000, 192, 768), ("patch wgrad", 70000, 384, 192),
     ("dec embed wgrad", 72000, 192, 384), ("pred wgrad", 218000, 192, 192),
 ]
-MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5}
+MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5, "gelu_act": 6}
 
 
 def wgrad_main(args, dev):
