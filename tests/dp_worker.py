@@ -22,7 +22,7 @@ def main() -> None:
     ap.add_argument("--world", type=int, required=True)
     ap.add_argument("--port", type=int, default=29511)
     ap.add_argument("--out", required=True)
-    ap.add_argument("--config", default="micro", choices=["micro", "vits8"])
+    ap.add_argument("--config", default="micro", choices=["micro", "vits8", "ijepa"])
     ap.add_argument("--precision", default="fp32")
     ap.add_argument("--global-batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=2)
@@ -30,7 +30,7 @@ def main() -> None:
 
     import torch
     import torch.distributed as dist
-    from ssrl_vit_mae_jepa_amd import MAEPretrainModule
+    from ssrl_vit_mae_jepa_amd import IJEPAPretrainModule, MAEPretrainModule
     from ssrl_vit_mae_jepa_amd import dist as mdist
 
     if a.world > 1:
@@ -38,8 +38,9 @@ def main() -> None:
         dist.init_process_group("gloo")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    if a.config == "micro":
-        general = dict(image_size=32, patch_size=8, in_chans=3, mask_ratio=0.75)
+    jepa = a.config == "ijepa"
+    if a.config in ("micro", "ijepa"):
+        general = dict(image_size=32, patch_size=8 if not jepa else 4, in_chans=3, mask_ratio=0.75)
         encoder, decoder = dict(embed_dim=48, depth=3, num_heads=2), dict(decoder_embed_dim=64, decoder_depth=1, decoder_num_heads=2)
     else:
         general = dict(image_size=96, patch_size=8, in_chans=3, mask_ratio=0.75)
@@ -47,28 +48,45 @@ def main() -> None:
     general["engine_precision"] = a.precision
     tcfg = dict(mask_ratio_start=0.75, mask_ratio_end=0.75, mask_ramp_epochs=5, total_epochs=800, warmup_epochs=20,
                 batch_size=2000, base_learning_rate=1.5e-4, weight_decay=0.05)
-    module = MAEPretrainModule(dict(general=general, encoder=encoder, decoder=decoder), tcfg)
-    module.model._init_weights(seed=73)  # identical parameters on every rank
+    if jepa:  # the I-JEPA step shares the exchange (gradient-ready events, buckets, loss slot) with the MAE step
+        module = IJEPAPretrainModule(dict(general=general, encoder=encoder, predictor=dict(pred_embed_dim=32, pred_depth=1, pred_num_heads=2)),
+                                     dict(tcfg, steps_per_epoch=4, ema_start=0.9))
+        net = module.model.net
+    else:
+        module = MAEPretrainModule(dict(general=general, encoder=encoder, decoder=decoder), tcfg)
+        net = module.model
+    net._init_weights(seed=73)  # identical parameters on every rank
     with torch.no_grad():  # non-zero biases / LayerNorm affine so every gradient term is exercised
         g = torch.Generator().manual_seed(7)
-        for n, p in module.model.named_parameters():
+        for n, p in net.named_parameters():
             if p.requires_grad and p.dim() == 1:
                 p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    if jepa:
+        module.model.reset_target()
     module = module.to(dev)
     module.on_train_epoch_start()
     model = module.model
-    B, L = a.global_batch, model.sequence_length
+    B = a.global_batch
     gi = torch.Generator().manual_seed(100)
     images = (torch.rand(B, 3, general["image_size"], general["image_size"], generator=gi) * 2 - 1).to(dev)
     losses, keep0 = [], None
     for step in range(a.steps):
-        noise = mdist.global_noise(B, L, 73, step, dev)
-        my_images, my_noise = mdist.shard_rows(images, a.rank, a.world), mdist.shard_rows(noise, a.rank, a.world)
-        if step == 0:
-            keep0 = model.random_token_mask(my_images.shape[0], my_noise)[0].cpu()
-        losses.append(module.fused_training_step(my_images, my_noise).clone())
+        my_images = mdist.shard_rows(images, a.rank, a.world)
+        if jepa:
+            ctx, tgt = model.sample_masks(B, torch.Generator().manual_seed(step))  # masks of the global batch, own rows kept
+            my_ctx, my_tgt = mdist.shard_rows(ctx, a.rank, a.world), mdist.shard_rows(tgt, a.rank, a.world)
+            if step == 0:
+                keep0 = my_ctx.clone()
+            losses.append(module.fused_training_step(my_images, my_ctx, my_tgt).clone())
+        else:
+            noise = mdist.global_noise(B, model.sequence_length, 73, step, dev)
+            my_noise = mdist.shard_rows(noise, a.rank, a.world)
+            if step == 0:
+                keep0 = model.random_token_mask(my_images.shape[0], my_noise)[0].cpu()
+            losses.append(module.fused_training_step(my_images, my_noise).clone())
     torch.cuda.synchronize()
     out = {"params": model.flat_params.detach().cpu(), "losses": torch.cat(losses).cpu(), "keep0": keep0,
+           "target": model.target_arena.detach().cpu() if jepa else torch.zeros(1),
            "stats": module._stats.cpu(), "buckets": module.gradient_buckets() if a.world > 1 else [],
            "overlap": module.overlap_exchange}
     torch.save(out, f"{a.out}/w{a.world}_r{a.rank}.pt")

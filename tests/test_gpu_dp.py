@@ -49,12 +49,12 @@ def _run(out, world, config, precision, batch, env_extra):
     return [torch.load(out / f"w{world}_r{r}.pt", weights_only=True) for r in range(world)]
 
 
-@pytest.mark.parametrize("config,precision,batch,tol", [("micro", "fp32", 8, 1e-5), ("vits8", "bf16", 8, 2e-4)])
+@pytest.mark.parametrize("config,precision,batch,tol", [("micro", "fp32", 8, 1e-5), ("vits8", "bf16", 8, 2e-4), ("ijepa", "fp32", 8, 2e-4)])
 def test_two_rank_product_step_equals_single_process(tmp_path, config, precision, batch, tol):
     a, b, c = tmp_path / "overlap", tmp_path / "blocking", tmp_path / "single"
     for d in (a, b, c):
         d.mkdir()
-    small = "0.01" if config == "micro" else "8"   # several buckets even for the micro model
+    small = "8" if config == "vits8" else "0.01"   # several buckets even for the micro models
     ov = _run(a, 2, config, precision, batch, {"MAE_DP_OVERLAP": "1", "MAE_DP_BUCKET_MB": small})
     bl = _run(b, 2, config, precision, batch, {"MAE_DP_OVERLAP": "0"})
     one = _run(c, 1, config, precision, batch, {})[0]
@@ -69,6 +69,9 @@ def test_two_rank_product_step_equals_single_process(tmp_path, config, precision
     assert torch.equal(ov[0]["stats"], bl[0]["stats"])
     # == the single-process full-batch step
     assert rel_err(ov[0]["params"], one["params"]) < tol
+    if config == "ijepa":  # the EMA target follows the reduced update on every rank
+        assert torch.equal(ov[0]["target"], ov[1]["target"]) and torch.equal(ov[0]["target"], bl[0]["target"])
+        assert rel_err(ov[0]["target"], one["target"]) < tol
     assert not torch.equal(one["params"], torch.zeros_like(one["params"]))
     assert torch.equal(torch.cat([ov[0]["keep0"], ov[1]["keep0"]]), one["keep0"])          # masks bit-equal
     assert torch.equal(ov[0]["losses"], ov[1]["losses"])                                   # the global mean on every rank

@@ -178,3 +178,30 @@ def test_error_behaviour(dev):
         model.loss_and_grads(images, torch.ones(2, 3, dtype=torch.int64), torch.ones(3, 1, 2, dtype=torch.int64))
     with pytest.raises(ValueError):
         IJEPA(dict(image_size=32, patch_size=4, loss="huber"), dict(embed_dim=48, depth=1, num_heads=2), dict(pred_embed_dim=32, pred_depth=1, pred_num_heads=2))
+
+
+def test_pretrain_cli_synthetic_run_and_resume(dev, tmp_path, monkeypatch):
+    """The I-JEPA harness (no reference counterpart): same flags and output tree as the MAE entry point."""
+    import json
+    import yaml
+    from pathlib import Path
+    from scripts.training import pretrain_ijepa as cli
+    cfg = yaml.safe_load(open(Path(__file__).resolve().parents[1] / "configs" / "ijepa_vits8.yaml"))
+    cfg["model"]["encoder"].update(embed_dim=64, depth=2, num_heads=2)
+    cfg["model"]["predictor"].update(pred_embed_dim=32, pred_depth=1, pred_num_heads=2)
+    cfg["pretrain"].update(batch_size=32, total_epochs=3, warmup_epochs=2, steps_per_epoch=4)
+    cfg["logging"]["output_dir_base"] = str(tmp_path / "outputs")
+    cfg_path = tmp_path / "ijepa.yaml"
+    yaml.safe_dump(cfg, open(cfg_path, "w"))
+    monkeypatch.chdir(tmp_path)
+    cli.main(["--config", str(cfg_path), "--output_dir_suffix", "t", "--synthetic_images", "128", "--max_epochs", "2"])
+    out = tmp_path / "outputs" / "pretrain" / "t"
+    ck = torch.load(out / "checkpoints" / "last.ckpt", weights_only=True)
+    assert ck["epoch"] == 1 and "model.target_arena" in ck["state_dict"] and "model.net.encoder.vit.blocks.0.attn.qkv.weight" in ck["state_dict"]
+    assert all(float(st["step"]) == ck["global_step"] for st in ck["optimizer_states"][0]["state"].values())
+    raw = torch.load(out / "vit-ijepa.pt", weights_only=True)
+    assert "target_encoder.vit.blocks.1.mlp.fc2.weight" in raw and "decoder.decoder_pred.weight" in raw
+    assert not torch.equal(raw["target_encoder.vit.blocks.0.mlp.fc1.weight"], raw["encoder.vit.blocks.0.mlp.fc1.weight"])  # the EMA lags
+    cli.main(["--config", str(cfg_path), "--output_dir_suffix", "t", "--synthetic_images", "128", "--resume_from", str(out / "checkpoints" / "last.ckpt")])
+    recs = [json.loads(x) for x in (out / "logs" / "metrics.jsonl").read_text().strip().splitlines()]
+    assert len(recs) == 3 and all(r["train_loss"] > 0 and r["val_loss"] > 0 for r in recs) and recs[2]["ema_momentum"] > recs[0]["ema_momentum"]
