@@ -205,3 +205,24 @@ def test_pretrain_cli_synthetic_run_and_resume(dev, tmp_path, monkeypatch):
     cli.main(["--config", str(cfg_path), "--output_dir_suffix", "t", "--synthetic_images", "128", "--resume_from", str(out / "checkpoints" / "last.ckpt")])
     recs = [json.loads(x) for x in (out / "logs" / "metrics.jsonl").read_text().strip().splitlines()]
     assert len(recs) == 3 and all(r["train_loss"] > 0 and r["val_loss"] > 0 for r in recs) and recs[2]["ema_momentum"] > recs[0]["ema_momentum"]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# committed vectors (tests/golden/jepa_micro.npz): the fp32 engine on committed images / masks, against committed outputs
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,loss", [("b3_mse", "mse"), ("b4_sl1", "smooth_l1")])
+def test_fp32_engine_matches_committed_golden(dev, tag, loss):
+    import numpy as np
+    from pathlib import Path
+    gold = np.load(Path(__file__).parent / "golden" / "jepa_micro.npz")
+    G = lambda k: torch.from_numpy(gold[f"{tag}/{k}"])  # noqa: E731
+    cfg = J.JEPA_MICRO
+    model, params, target = build(cfg, "fp32", dev, loss)     # same weight recipe as tests/golden/make_golden_jepa.py
+    l, h, pred = model.loss_and_grads(G("images").to(dev), G("idx_context"), G("idx_target"), return_aux=True)
+    assert abs(l.item() - float(G("loss"))) <= 1e-4 * float(G("loss"))
+    assert rel_err(h, G("h")) < 1e-4 and rel_err(pred, G("pred")) < 1e-4
+    g = model.named_flat_views(model.flat_grads)
+    assert rel_err(torch.stack([g[n].norm() for n in J.trainable_names(cfg)]), G("grad_norms")) < 3e-4
+    for k in gold.files:
+        if k.startswith(f"{tag}/grad/"):
+            assert rel_err(g[k.split("/", 2)[2]], torch.from_numpy(gold[k])) < 3e-4, k

@@ -39,3 +39,47 @@ def test_tie_case_contract():
     keep, mask = O.mask_from_noise(noise, 4)  # lightly's (unstable) argsort: same keys position by position
     got = torch.cat([keep, mask], 1)
     assert torch.equal(torch.gather(ref, 1, got), torch.gather(ref, 1, stable))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# I-JEPA (tests/golden/jepa_micro.npz, made by tests/golden/make_golden_jepa.py; parity unpinned: no reference code)
+# ----------------------------------------------------------------------------------------------------------------------
+from oracle import jepa_oracle as J  # noqa: E402
+from tests.golden.make_golden_jepa import weights as jepa_weights  # noqa: E402
+
+JGOLD = np.load(Path(__file__).parent / "golden" / "jepa_micro.npz")
+
+
+@pytest.mark.parametrize("tag,seed,loss", [("b3_mse", 21, "mse"), ("b4_sl1", 22, "smooth_l1")])
+def test_jepa_oracle_reproduces_golden(tag, seed, loss):
+    G = lambda k: torch.from_numpy(JGOLD[f"{tag}/{k}"])  # noqa: E731
+    cfg = J.JEPAConfig(**{**J.JEPA_MICRO.__dict__, "loss": loss})
+    params, target = jepa_weights(cfg)
+    images = G("images")
+    ctx, tgt = J.sample_masks(cfg, images.shape[0], torch.Generator().manual_seed(seed + 1))
+    assert torch.equal(ctx, G("idx_context")) and torch.equal(tgt, G("idx_target"))          # integer-exact
+    l, grads, aux = J.loss_and_grads(params, target, cfg, images, ctx, tgt)
+    assert torch.allclose(l, G("loss"), rtol=1e-6)
+    assert torch.allclose(aux["h"], G("h"), rtol=1e-5, atol=1e-6) and torch.allclose(aux["pred"], G("pred"), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(torch.stack([g.norm() for g in grads.values()]), G("grad_norms"), rtol=1e-4)
+    for k in JGOLD.files:
+        if k.startswith(f"{tag}/grad/"):
+            assert torch.allclose(grads[k.split("/", 2)[2]], torch.from_numpy(JGOLD[k]), rtol=1e-4, atol=1e-7), k
+    state = {}
+    for step in (1, 2):
+        J.train_step(params, target, cfg, state, images, ctx, tgt, 1e-3, step, 0.99)
+    assert torch.allclose(torch.stack([params[n].norm() for n in J.trainable_names(cfg)]), G("param_norms_after_2_steps"), rtol=1e-5)
+    assert torch.allclose(torch.stack([target[n].norm() for n in J.ema_names(cfg)]), G("target_norms_after_2_steps"), rtol=1e-5)
+
+
+def test_product_mask_sampler_reproduces_golden_ids():
+    """The vectorised host sampler the product ships (ssrl_vit_mae_jepa_amd/jepa.py) returns the committed ids."""
+    from ssrl_vit_mae_jepa_amd.jepa import sample_block_masks
+    c = J.JEPA_VIT_S8
+    ctx, tgt = sample_block_masks(6, c.grid, torch.Generator().manual_seed(3), c.num_target_blocks, c.target_scale, c.target_aspect, c.context_scale)
+    assert torch.equal(ctx, torch.from_numpy(JGOLD["sampler_vits8/idx_context"]))
+    assert torch.equal(tgt, torch.from_numpy(JGOLD["sampler_vits8/idx_target"]))
+    m = J.JEPA_MICRO
+    for tag, seed, B in (("b3_mse", 21, 3), ("b4_sl1", 22, 4)):
+        ctx, tgt = sample_block_masks(B, m.grid, torch.Generator().manual_seed(seed + 1), m.num_target_blocks, m.target_scale, m.target_aspect, m.context_scale)
+        assert torch.equal(ctx, torch.from_numpy(JGOLD[f"{tag}/idx_context"])) and torch.equal(tgt, torch.from_numpy(JGOLD[f"{tag}/idx_target"]))
