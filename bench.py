@@ -198,7 +198,8 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_group = os.environ.get("MAE_DP_FORCE_EXCHANGE") == "1" and "MASTER_ADDR" in os.environ  # one-rank RCCL rehearsal under torchrun
+    if world > 1 or force_group:
         if args.backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
@@ -254,7 +255,7 @@ def main() -> None:
         step_fn = lambda i: module.fused_training_step(images, noises[i])  # noqa: E731
 
     def sync():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -273,7 +274,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))]  # noqa: E731
-    if world > 1:
+    if torch.distributed.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -334,7 +335,7 @@ def main() -> None:
             out["cpu_baseline"] = (jepa_cpu_baseline(general, encoder, predictor, label, batch=32 if img <= 96 else 4) if predictor
                                    else cpu_baseline(general, encoder, decoder, label, batch=64 if img <= 96 else 8))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -175,8 +175,8 @@ class MAEPretrainModule(nn.Module):
         dev = model._require_cuda()
         dist = torch.distributed
         world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        if world == 1:
-            return compute(1.0, None, None)
+        if world == 1 and not (dist.is_available() and dist.is_initialized() and os.environ.get("MAE_DP_FORCE_EXCHANGE") == "1"):
+            return compute(1.0, None, None)  # (MAE_DP_FORCE_EXCHANGE=1: rehearse the exchange on a one-rank RCCL group)
         n = model.engine.trainable_elems
         buf = model.grad_buffer
         loss_slot = buf[n:n + 1]
