@@ -411,6 +411,20 @@ constexpr int T2_GPW = 6, T2_NI = 3, T2_KI = 6, T2_CPR = T2_RS / 16;  // 24 16-b
 __device__ __forceinline__ void tn_glds16(const bf16* src, char* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
+// The same DMA as one opaque instruction pair.  hipcc's waitcnt pass knows that the builtin writes LDS and, because the
+// transposed-read builtin carries no alias information, puts `s_waitcnt vmcnt(0)` in front of the first ds_read_b64_tr_b16
+// after every DMA issue -- which drains the two-steps-ahead ring at every step (the DMA phase and the MFMA phase of the
+// wgrad kernel added up for exactly this reason).  Issued from inline asm the DMA is invisible to that pass; the counted
+// tn_wait_vm<> + barrier below are what orders it against the reads, checked against the all-drained build
+// (MAE_DBG_VMCNT0) like the NT kernel's.  m0 is written behind the compiler's back: nothing else in these kernels uses it.
+__device__ __forceinline__ void tn_glds16_raw(const bf16* src, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory");
+}
+template <bool RAW>
+__device__ __forceinline__ void tn_dma(const bf16* src, char* dst) {
+  if (RAW) tn_glds16_raw(src, (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)dst));
+  else tn_glds16(src, dst);
+}
 template <int N_>
 __device__ __forceinline__ void tn_wait_vm() {
 #ifdef MAE_DBG_VMCNT0  // see wait_vm() in k_gemm_mfma2.hip: the all-drained build the counted waits are checked against
@@ -420,6 +434,7 @@ __device__ __forceinline__ void tn_wait_vm() {
 #endif
 }
 
+template <bool RAW>
 __global__ void __launch_bounds__(512, 2) gemm_tn2_kernel(const bf16* __restrict__ dY, const bf16* __restrict__ X, int64_t M, int N, int K,
                                                           float* __restrict__ out, float* __restrict__ db, int64_t split_stride,
                                                           int tiles_n, int tiles_k, int64_t m_chunk) {
@@ -465,11 +480,11 @@ __global__ void __launch_bounds__(512, 2) gemm_tn2_kernel(const bf16* __restrict
 #pragma unroll
       for (int q = 0; q < T2_GPW; ++q) {
         const int64_t m = mb + (row_[q] < last_valid ? row_[q] : last_valid - 1);
-        tn_glds16(gbase + m * ld + sc_[q], dst + q * 1024);
+        tn_dma<RAW>(gbase + m * ld + sc_[q], dst + q * 1024);
       }
     } else {
-      tn_glds16(p0, dst); tn_glds16(p1, dst + 1024); tn_glds16(p2, dst + 2048);
-      tn_glds16(p3, dst + 3072); tn_glds16(p4, dst + 4096); tn_glds16(p5, dst + 5120);
+      tn_dma<RAW>(p0, dst); tn_dma<RAW>(p1, dst + 1024); tn_dma<RAW>(p2, dst + 2048);
+      tn_dma<RAW>(p3, dst + 3072); tn_dma<RAW>(p4, dst + 4096); tn_dma<RAW>(p5, dst + 5120);
       p0 += inc; p1 += inc; p2 += inc; p3 += inc; p4 += inc; p5 += inc;
     }
     is_stage = is_stage == T2_NSTAGE - 1 ? 0 : is_stage + 1;
@@ -599,8 +614,188 @@ __global__ void __launch_bounds__(512, 2) gemm_tn2_kernel(const bf16* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad v3 (the default; MAE_WGRAD=v2 selects the kernel above): the v2 tile, ring and LDS image with ONE barrier per step and all eight waves in
+// phase; the fragment reads are software-pipelined ACROSS the barrier instead of ping-ponged between wave groups:
+//     step st:  wait DMA(st) | lgkmcnt(0) | barrier | DMA(st+2) -> the stage read during step st-1
+//               reads (st, rows 0-31)  interleaved 1:1 with the MFMAs of (st-1, rows 32-63)
+//               reads (st, rows 32-63) interleaved 1:1 with the MFMAs of (st,   rows 0-31)
+// Every accumulator sees the same products in the same order as in v2, so the two kernels agree bit for bit.
+// ---------------------------------------------------------------------------------------------------
+template <bool RAW>
+__global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict__ dY, const bf16* __restrict__ X, int64_t M, int N, int K,
+                                                          float* __restrict__ out, float* __restrict__ db, int64_t split_stride,
+                                                          int tiles_n, int tiles_k, int64_t m_chunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int vb = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = vb % (tiles_n * tiles_k);
+  const int split = vb / (tiles_n * tiles_k);
+  const int n0 = (tile / tiles_k) * T2, k0 = (tile % tiles_k) * T2;
+  const int64_t mbeg = (int64_t)split * m_chunk;
+  const int64_t mend = mbeg + m_chunk < M ? mbeg + m_chunk : M;
+  const int nsteps = mend > mbeg ? (int)((mend - mbeg + T2_BR - 1) / T2_BR) : 0;
+  const int last_valid = nsteps ? (int)(mend - mbeg - (int64_t)(nsteps - 1) * T2_BR) : 0;
+
+  const bool isY = wave >= 4;
+  const bf16* gbase = isY ? dY + n0 : X + k0;
+  const int64_t ld = isY ? N : K;
+  int row_[T2_GPW], sc_[T2_GPW];
+#pragma unroll
+  for (int q = 0; q < T2_GPW; ++q) {
+    const int c = ((wave & 3) * T2_GPW + q) * 64 + lane;
+    const int row = c / T2_CPR, slot = c % T2_CPR;
+    row_[q] = row;
+    sc_[q] = ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1)) * 8;
+  }
+  const bf16 *p0 = gbase + (mbeg + row_[0]) * ld + sc_[0], *p1 = gbase + (mbeg + row_[1]) * ld + sc_[1],
+             *p2 = gbase + (mbeg + row_[2]) * ld + sc_[2], *p3 = gbase + (mbeg + row_[3]) * ld + sc_[3],
+             *p4 = gbase + (mbeg + row_[4]) * ld + sc_[4], *p5 = gbase + (mbeg + row_[5]) * ld + sc_[5];
+  const int64_t inc = (int64_t)T2_BR * ld;
+  int is_step = 0, is_stage = 0;
+  auto issue = [&]() {
+    char* dst = smem + is_stage * T2_STAGE + (isY ? T2_HALF : 0) + (wave & 3) * (T2_GPW * 1024);
+    if (is_step == nsteps - 1 && last_valid < T2_BR) {
+      const int64_t mb = mbeg + (int64_t)is_step * T2_BR;
+#pragma unroll
+      for (int q = 0; q < T2_GPW; ++q) {
+        const int64_t m = mb + (row_[q] < last_valid ? row_[q] : last_valid - 1);
+        tn_dma<RAW>(gbase + m * ld + sc_[q], dst + q * 1024);
+      }
+    } else {
+      tn_dma<RAW>(p0, dst); tn_dma<RAW>(p1, dst + 1024); tn_dma<RAW>(p2, dst + 2048);
+      tn_dma<RAW>(p3, dst + 3072); tn_dma<RAW>(p4, dst + 4096); tn_dma<RAW>(p5, dst + 5120);
+      p0 += inc; p1 += inc; p2 += inc; p3 += inc; p4 += inc; p5 += inc;
+    }
+    is_stage = is_stage == T2_NSTAGE - 1 ? 0 : is_stage + 1;
+    ++is_step;
+  };
+
+  f32x4 acc[T2_KI][T2_NI], accb[T2_NI];
+#pragma unroll
+  for (int i = 0; i < T2_KI; ++i)
+#pragma unroll
+    for (int j = 0; j < T2_NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < T2_NI; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = db != nullptr && k0 == 0 && wk == 0;
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
+
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p = lane & 3;
+  const int sw = ((g & 1) << 1) | (q4 >> 1);
+  const int lane_off = (4 * g + q4) * T2_RS + p * 8;
+  int yo[T2_NI], xo[T2_KI];
+#pragma unroll
+  for (int ni = 0; ni < T2_NI; ++ni) yo[ni] = T2_HALF + lane_off + (((wn * T2_NI + ni) ^ sw) * 32);
+#pragma unroll
+  for (int ki = 0; ki < T2_KI; ++ki) xo[ki] = lane_off + (((wk * T2_KI + ki) ^ sw) * 32);
+
+  bf16x8 yf[2][T2_NI], xf[2][T2_KI];
+#define TN3_READ(sb, h)                                                                                 \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni) {                                              \
+      const bf16x4 lo = lds_read_tr((sb) + yo[ni] + (32 * (h)) * T2_RS);                                \
+      const bf16x4 hi = lds_read_tr((sb) + yo[ni] + (32 * (h) + 16) * T2_RS);                           \
+      yf[h][ni] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                       \
+    }                                                                                                   \
+    _Pragma("unroll") for (int ki = 0; ki < T2_KI; ++ki) {                                              \
+      const bf16x4 lo = lds_read_tr((sb) + xo[ki] + (32 * (h)) * T2_RS);                                \
+      const bf16x4 hi = lds_read_tr((sb) + xo[ki] + (32 * (h) + 16) * T2_RS);                           \
+      xf[h][ki] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                       \
+    }                                                                                                   \
+  }
+#define TN3_MFMA(h)                                                                                     \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ki = 0; ki < T2_KI; ++ki)                                                \
+      _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                              \
+        acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[h][ki], yf[h][ni], acc[ki][ni], 0, 0, 0); \
+  }
+#define TN3_BIAS(h)                                                                                     \
+  if (do_bias) {                                                                                        \
+    _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                                \
+      accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[h][ni], accb[ni], 0, 0, 0);           \
+  }
+#define TN3_INTERLEAVE()                                                                                \
+  {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < T2_KI * T2_NI; ++i) {                                         \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
+    }                                                                                                   \
+  }
+#define TN3_STEP_TOP(st)                                                                                \
+    if ((st) + 1 < nsteps) tn_wait_vm<T2_GPW>(); else tn_wait_vm<0>();                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's reads of the stage refilled below have landed */ \
+    __builtin_amdgcn_s_barrier();                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    asm volatile("" ::: "memory");                                                                      \
+    const char* sb = smem + cs * T2_STAGE;                                                              \
+    if ((st) == nsteps - 1 && last_valid < T2_BR) {                                                     \
+      for (int i = tid; i < (T2_BR - last_valid) * T2_CPR; i += 512)                                    \
+        *reinterpret_cast<uint4*>(smem + cs * T2_STAGE + T2_HALF + (last_valid + i / T2_CPR) * T2_RS + (i % T2_CPR) * 16) = uint4{0, 0, 0, 0}; \
+      __syncthreads();                                                                                  \
+    }                                                                                                   \
+    if ((st) + 2 < nsteps) issue();                                                                     \
+    __builtin_amdgcn_sched_barrier(0);
+  int cs = 0;
+  if (nsteps > 0) {
+    issue();
+    if (nsteps > 1) issue();
+    {  // step 0: nothing to multiply yet while the first half is read
+      TN3_STEP_TOP(0)
+      TN3_READ(sb, 0)
+      __builtin_amdgcn_sched_barrier(0);
+      TN3_READ(sb, 1)
+      TN3_MFMA(0)
+      TN3_INTERLEAVE()
+      __builtin_amdgcn_sched_barrier(0);
+      TN3_BIAS(0)
+      cs = 1;
+    }
+    for (int st = 1; st < nsteps; ++st) {
+      TN3_STEP_TOP(st)
+      TN3_READ(sb, 0)
+      TN3_MFMA(1)
+      TN3_INTERLEAVE()
+      __builtin_amdgcn_sched_barrier(0);
+      TN3_BIAS(1)
+      __builtin_amdgcn_sched_barrier(0);
+      TN3_READ(sb, 1)
+      TN3_MFMA(0)
+      TN3_INTERLEAVE()
+      __builtin_amdgcn_sched_barrier(0);
+      TN3_BIAS(0)
+      cs = cs == T2_NSTAGE - 1 ? 0 : cs + 1;
+    }
+    TN3_MFMA(1)
+    TN3_BIAS(1)
+  }
+#undef TN3_STEP_TOP
+#undef TN3_INTERLEAVE
+#undef TN3_BIAS
+#undef TN3_MFMA
+#undef TN3_READ
+  float* o = out + (int64_t)split * split_stride;
+  if (do_bias && lane < 16) {
+#pragma unroll
+    for (int ni = 0; ni < T2_NI; ++ni) db[(int64_t)split * split_stride + n0 + wn * (T2_NI * 16) + ni * 16 + lane] = accb[ni][0];
+  }
+#pragma unroll
+  for (int ni = 0; ni < T2_NI; ++ni) {
+    const int n = n0 + wn * (T2_NI * 16) + ni * 16 + (lane & 15);
+#pragma unroll
+    for (int ki = 0; ki < T2_KI; ++ki) {
+      const int k = k0 + wk * (T2_KI * 16) + ki * 16 + (lane >> 4) * 4;
+      store4(o + (int64_t)n * K + k, acc[ki][ni]);
+    }
+  }
+}
+
 static bool wgrad2_ok(int64_t M, int N, int K) {
-  static const bool off = [] { const char* v = getenv("MAE_WGRAD"); return v && v[0] == 'v' && v[1] == '1'; }();
+  const char* v = getenv("MAE_WGRAD");  // v1: the register-staged 128 x 128 tiles everywhere (A/B switch, read per call)
+  const bool off = v && v[0] == 'v' && v[1] == '1';
   return !off && N % T2 == 0 && K % T2 == 0 && M >= 4096;
 }
 static int wgrad2_splits(int64_t M, int N, int K) {
@@ -678,8 +873,12 @@ int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, fl
   if (v2) {
     const int tiles_n = N / T2, tiles_k = K / T2;
     const int lds = T2_NSTAGE * T2_STAGE;
-    MAE_HIP(hipFuncSetAttribute((const void*)gemm_tn2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(gemm_tn2_kernel, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(512), lds, s, dY, X, M, N, K, out, dbo, stride, tiles_n, tiles_k, m_chunk);
+    const char* ev = getenv("MAE_WGRAD");  // A/B switch (tools/gemm_bench.py --wgrad): v2 | v2r | v3 | v3r (default); r = DMA issued from inline asm
+    const bool sel = ev && ev[0] == 'v' && (ev[1] == '2' || ev[1] == '3');
+    const bool k3 = !sel || ev[1] == '3', raw = !sel || ev[2] == 'r';
+    auto kern = k3 ? (raw ? gemm_tn3_kernel<true> : gemm_tn3_kernel<false>) : (raw ? gemm_tn2_kernel<true> : gemm_tn2_kernel<false>);
+    MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(512), lds, s, dY, X, M, N, K, out, dbo, stride, tiles_n, tiles_k, m_chunk);
     MAE_LAUNCH_CHECK();
     r = 0;
   } else if (N % 64 != 0 || K % 64 != 0) {

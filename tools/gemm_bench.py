@@ -44,28 +44,37 @@ MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5, 
 
 
 def wgrad_main(args, dev):
+    """Interleaved A/B of the wgrad kernel variants (MAE_WGRAD, read per call) with a bitwise comparison against the first."""
+    variants = args.wgrad_variants.split(",")
     g = torch.Generator(device=dev).manual_seed(1)
     for name, M, N, K in WGRAD_SHAPES:
         if args.only and args.only not in name:
             continue
         dY = (torch.rand(M, N, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
         A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
-        dW = torch.empty(N, K, device=dev)
-        db = torch.empty(N, device=dev)
+        outs = {v: (torch.empty(N, K, device=dev), torch.empty(N, device=dev)) for v in variants}
         scratch = torch.empty(max(1, lib.mae_linear_wgrad_scratch_bytes(M, N, K)), dtype=torch.uint8, device=dev)
 
-        def run():
+        def run(v):
+            os.environ["MAE_WGRAD"] = v
+            dW, db = outs[v]
             check(lib.mae_linear_wgrad(_ptr(dY), _ptr(A), M, N, K, BF16, _ptr(dW), _ptr(db), _ptr(scratch), stream(dev)))
-        run()
+        for v in variants:
+            run(v)
         torch.cuda.synchronize()
-        times = []
+        times = {v: [] for v in variants}
         for _ in range(args.rounds):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); run(); e1.record(); torch.cuda.synchronize()
-            times.append(e0.elapsed_time(e1) * 1e3)
-        t = sorted(times)[len(times) // 2]
-        nbytes = M * (N + K) * 2 + N * K * 4
-        print(f"{name:18s} M={M} N={N} K={K} | {t:7.1f} us {2 * M * N * K / t / 1e6:6.0f} TF/s {nbytes / t / 1e3:5.0f} GB/s (operands once) scratch {scratch.numel() / 1e6:.1f} MB", flush=True)
+            for v in variants:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); run(v); e1.record(); torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) * 1e3)
+        line = f"{name:18s} M={M} N={N} K={K}"
+        for v in variants:
+            t = sorted(times[v])[len(times[v]) // 2]
+            same = "" if v == variants[0] else (" ==" if torch.equal(outs[v][0], outs[variants[0]][0]) and torch.equal(outs[v][1], outs[variants[0]][1]) else " DIFFERS")
+            line += f" | {v}: {t:7.1f} us {2 * M * N * K / t / 1e6:5.0f} TF/s{same}"
+        print(line, flush=True)
+    os.environ.pop("MAE_WGRAD", None)
 
 
 def main():
@@ -74,6 +83,7 @@ def main():
     ap.add_argument("--variants", default="v1,v2")
     ap.add_argument("--only", default=None)
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient GEMM (+ slab reduce) instead")
+    ap.add_argument("--wgrad-variants", default="v2", help="comma list of MAE_WGRAD values to A/B (v1 | v2 | v2r | v3 | v3r)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.wgrad:
