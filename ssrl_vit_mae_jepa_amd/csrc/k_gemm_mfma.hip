@@ -656,6 +656,9 @@ __global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict
   const int64_t inc = (int64_t)T2_BR * ld;
   int is_step = 0, is_stage = 0;
   auto issue = [&]() {
+#ifdef MAE_DBG_TN_NO_LOAD   // phase ablation builds (tools/build_dbg_lib.sh tn_no_load tn_no_mfma tn3_nosched): timing probes, wrong values
+    return;
+#endif
     char* dst = smem + is_stage * T2_STAGE + (isY ? T2_HALF : 0) + (wave & 3) * (T2_GPW * 1024);
     if (is_step == nsteps - 1 && last_valid < T2_BR) {
       const int64_t mb = mbeg + (int64_t)is_step * T2_BR;
@@ -707,17 +710,24 @@ __global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict
       xf[h][ki] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                       \
     }                                                                                                   \
   }
+#ifdef MAE_DBG_TN_NO_MFMA
+#define TN3_MFMA(h) { asm volatile("" :: "v"(xf[h][0]), "v"(xf[h][1]), "v"(xf[h][2]), "v"(xf[h][3]), "v"(xf[h][4]), "v"(xf[h][5]), "v"(yf[h][0]), "v"(yf[h][1]), "v"(yf[h][2])); }
+#else
 #define TN3_MFMA(h)                                                                                     \
   {                                                                                                     \
     _Pragma("unroll") for (int ki = 0; ki < T2_KI; ++ki)                                                \
       _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                              \
         acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[h][ki], yf[h][ni], acc[ki][ni], 0, 0, 0); \
   }
+#endif
 #define TN3_BIAS(h)                                                                                     \
   if (do_bias) {                                                                                        \
     _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                                \
       accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[h][ni], accb[ni], 0, 0, 0);           \
   }
+#if defined(MAE_DBG_TN3_NOSCHED) || defined(MAE_DBG_TN_NO_MFMA)
+#define TN3_INTERLEAVE() {}
+#else
 #define TN3_INTERLEAVE()                                                                                \
   {                                                                                                     \
     _Pragma("unroll") for (int i = 0; i < T2_KI * T2_NI; ++i) {                                         \
@@ -725,6 +735,7 @@ __global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
     }                                                                                                   \
   }
+#endif
 #define TN3_STEP_TOP(st)                                                                                \
     if ((st) + 1 < nsteps) tn_wait_vm<T2_GPW>(); else tn_wait_vm<0>();                                  \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's reads of the stage refilled below have landed */ \
@@ -754,21 +765,51 @@ __global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict
       TN3_BIAS(0)
       cs = 1;
     }
+#ifdef MAE_DBG_TN3_TRACE   // cycle breakdown of a step (tools/build_dbg_lib.sh tn3_trace): prints from workgroup 0, perturbs the timing a little
+    uint64_t tr_bar = 0, tr_dma = 0, tr_p1 = 0, tr_p2 = 0, tr_prev = 0;
+#define TN3_TS(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+#endif
     for (int st = 1; st < nsteps; ++st) {
+#ifdef MAE_DBG_TN3_TRACE
+      uint64_t ta, tb, tc, td, te;
+      TN3_TS(ta)
+      if ((st) + 1 < nsteps) tn_wait_vm<T2_GPW>(); else tn_wait_vm<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      const char* sb = smem + cs * T2_STAGE;
+      TN3_TS(tb)
+      if ((st) + 2 < nsteps) issue();
+      TN3_TS(tc)
+#else
       TN3_STEP_TOP(st)
+#endif
       TN3_READ(sb, 0)
       TN3_MFMA(1)
       TN3_INTERLEAVE()
       __builtin_amdgcn_sched_barrier(0);
       TN3_BIAS(1)
       __builtin_amdgcn_sched_barrier(0);
+#ifdef MAE_DBG_TN3_TRACE
+      TN3_TS(td)
+#endif
       TN3_READ(sb, 1)
       TN3_MFMA(0)
       TN3_INTERLEAVE()
       __builtin_amdgcn_sched_barrier(0);
       TN3_BIAS(0)
+#ifdef MAE_DBG_TN3_TRACE
+      TN3_TS(te)
+      if (st >= 4 && st + 4 < nsteps) { tr_bar += tb - ta; tr_dma += tc - tb; tr_p1 += td - tc; tr_p2 += te - td; tr_prev += 1; }
+#endif
       cs = cs == T2_NSTAGE - 1 ? 0 : cs + 1;
     }
+#ifdef MAE_DBG_TN3_TRACE
+    if (blockIdx.x == 0 && lane == 0 && tr_prev)
+      printf("tn3 trace wave %d steps %d | wait+barrier %d | dma issue %d | phase1 (18 mfma + 18 reads) %d | phase2 %d cycles/step\n", wave, (int)tr_prev,
+             (int)(tr_bar / tr_prev), (int)(tr_dma / tr_prev), (int)(tr_p1 / tr_prev), (int)(tr_p2 / tr_prev));
+#endif
     TN3_MFMA(1)
     TN3_BIAS(1)
   }
