@@ -23,6 +23,8 @@ SHAPES = [  # name, M, N, K, epilogue, out dtype
     ("tgt fc1 fwd (gelu_act)", 288000, 1536, 384, "gelu_act", BF16),
     ("enc qkv dgrad", 72000, 384, 1152, "none", BF16),
     ("enc proj fwd resid", 72000, 384, 384, "resid", F32),
+    ("enc fc2 fwd resid", 72000, 384, 1536, "resid", F32),
+    ("dec fc2 fwd resid", 290000, 192, 768, "resid", F32),
     ("dec qkv fwd", 290000, 576, 192, "none", BF16),
     ("dec fc1 fwd (gelu)", 290000, 768, 192, "gelu", BF16),
     ("dec fc2 fwd", 290000, 192, 768, "none", BF16),
