@@ -649,6 +649,9 @@ __global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict
     const int row = c / T2_CPR, slot = c % T2_CPR;
     row_[q] = row;
     sc_[q] = ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1)) * 8;
+    // a last tile column that sticks out of the matrix (widths that are not multiples of 192): its chunks are fetched from the
+    // tile's first column instead (valid memory); they only ever reach accumulators whose stores are guarded out below
+    if (sc_[q] >= (isY ? N - n0 : K - k0)) sc_[q] = 0;
   }
   const bf16 *p0 = gbase + (mbeg + row_[0]) * ld + sc_[0], *p1 = gbase + (mbeg + row_[1]) * ld + sc_[1],
              *p2 = gbase + (mbeg + row_[2]) * ld + sc_[2], *p3 = gbase + (mbeg + row_[3]) * ld + sc_[3],
@@ -821,7 +824,10 @@ __global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict
   float* o = out + (int64_t)split * split_stride;
   if (do_bias && lane < 16) {
 #pragma unroll
-    for (int ni = 0; ni < T2_NI; ++ni) db[(int64_t)split * split_stride + n0 + wn * (T2_NI * 16) + ni * 16 + lane] = accb[ni][0];
+    for (int ni = 0; ni < T2_NI; ++ni) {
+      const int n = n0 + wn * (T2_NI * 16) + ni * 16 + lane;
+      if (n < N) db[(int64_t)split * split_stride + n] = accb[ni][0];
+    }
   }
 #pragma unroll
   for (int ni = 0; ni < T2_NI; ++ni) {
@@ -829,21 +835,46 @@ __global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict
 #pragma unroll
     for (int ki = 0; ki < T2_KI; ++ki) {
       const int k = k0 + wk * (T2_KI * 16) + ki * 16 + (lane >> 4) * 4;
-      store4(o + (int64_t)n * K + k, acc[ki][ni]);
+      if (n < N && k < K) store4(o + (int64_t)n * K + k, acc[ki][ni]);
     }
   }
 }
 
-static bool wgrad2_ok(int64_t M, int N, int K) {
-  const char* v = getenv("MAE_WGRAD");  // v1: the register-staged 128 x 128 tiles everywhere (A/B switch, read per call)
-  const bool off = v && v[0] == 'v' && v[1] == '1';
-  return !off && N % T2 == 0 && K % T2 == 0 && M >= 4096;
+// the 192 x 192 ring kernels: every width that is a multiple of 192, and (v3 only, whose loads and stores are guarded by column)
+// widths that fill their last tile column well enough -- 1024 = 5.33 tiles, 512 x 2048 = 3 x 11 tiles at 86 % -- to beat the
+// 128 x 128 register-staged kernel (measured 0.55-0.70 PF/s at 1024-wide layers against 0.9 PF/s x fill for this one)
+static bool wgrad2_shape_ok(int64_t M, int N, int K, bool* ragged = nullptr) {   // no environment in here: the scratch size depends on it
+  if (ragged) *ragged = false;
+  if (M < 4096) return false;
+  if (N % T2 == 0 && K % T2 == 0) return true;
+  if (N % 8 != 0 || K % 8 != 0 || N < T2 || K < T2) return false;
+  if (ragged) *ragged = true;
+  const int64_t tiles = (int64_t)cdiv(N, T2) * cdiv(K, T2);
+  return (int64_t)N * K * 100 >= tiles * T2 * T2 * 75;  // >= 75 % of the tile area is real
 }
+static bool wgrad2_ok(int64_t M, int N, int K) {
+  const char* v = getenv("MAE_WGRAD");  // A/B switch, read per call: v1 = register-staged tiles everywhere, v2 = the round-1 ring kernel
+  if (v && v[0] == 'v' && v[1] == '1') return false;
+  bool ragged = false;
+  if (!wgrad2_shape_ok(M, N, K, &ragged)) return false;
+  return !(ragged && v && v[0] == 'v' && v[1] == '2');  // only the v3 kernel guards its loads and stores by column
+}
+// Splits over M for the 192 x 192 ring kernels: one workgroup per CU is resident (144 KiB of LDS), so the launch runs in rounds
+// of num_cus() workgroups.  S minimises  rounds(S) x (time of one workgroup at S = 1) / S  +  S x (slab write + read time):
+// with few tiles that is the old rule S = CUs / tiles (one full round); with more tiles than half the CUs (1024-wide layers:
+// 132 tiles on 256 CUs left 48 % of the chip idle at S = 1) several rounds of shorter workgroups win.
 static int wgrad2_splits(int64_t M, int N, int K) {
-  const int64_t tiles = (int64_t)(N / T2) * (K / T2);
-  int64_t S = std::max<int64_t>(1, num_cus() / tiles);            // one block per CU (144 KiB of LDS)
-  S = std::min<int64_t>(S, std::max<int64_t>(1, M / 256));        // at least 4 reduction steps per block
-  return (int)S;
+  const int64_t tiles = (int64_t)cdiv(N, T2) * cdiv(K, T2), cus = num_cus();
+  const int64_t smax = std::min<int64_t>(512, std::max<int64_t>(1, M / 256));  // at least 4 reduction steps per block
+  const double t1 = (double)M / T2_BR * 1.5;                                    // us: ~1.5 us per 64-row step
+  const double slab = (double)N * K * 8.0 / 5.0e6;                              // us per split: fp32 partials written once, read once, ~5 TB/s
+  int best = 1;
+  double best_cost = 1e30;
+  for (int64_t S = 1; S <= smax; ++S) {
+    const double cost = (double)cdiv(tiles * S, cus) * t1 / (double)S + (double)S * slab;
+    if (cost < best_cost * 0.999) { best_cost = cost; best = (int)S; }
+  }
+  return best;
 }
 
 // ordered (deterministic) sum of the per-split slabs: [S][N*K weight partials | N bias partials].
@@ -883,7 +914,7 @@ static int wgrad_splits(int64_t M, int N, int K) {
 int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K) {
   if (N % 8 != 0 || K % 8 != 0) return 0;
   int S = wgrad_splits(M, N, K);
-  if (N % T2 == 0 && K % T2 == 0) S = std::max(S, wgrad2_splits(M, N, K));
+  if (wgrad2_shape_ok(M, N, K)) S = std::max(S, wgrad2_splits(M, N, K));  // whichever kernel the A/B switch selects at launch time fits
   return S > 1 ? round_up((int64_t)S * ((int64_t)N * K + N) * 4, 256) : 0;
 }
 
@@ -912,7 +943,7 @@ int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, fl
   const bool n128 = N % 128 == 0, k128 = K % 128 == 0;
   int r;
   if (v2) {
-    const int tiles_n = N / T2, tiles_k = K / T2;
+    const int tiles_n = (int)cdiv(N, T2), tiles_k = (int)cdiv(K, T2);
     const int lds = T2_NSTAGE * T2_STAGE;
     const char* ev = getenv("MAE_WGRAD");  // A/B switch (tools/gemm_bench.py --wgrad): v2 | v2r | v3 | v3r (default); r = DMA issued from inline asm
     const bool sel = ev && ev[0] == 'v' && (ev[1] == '2' || ev[1] == '3');

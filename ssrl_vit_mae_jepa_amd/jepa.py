@@ -170,6 +170,21 @@ class IJEPA(nn.Module):
             self._workspace = torch.empty(int(need * 1.25) if grown else need, dtype=torch.uint8, device=dev)
         return self._workspace
 
+    def reserve_workspace(self, batch: int, max_context: Optional[int] = None, num_blocks: Optional[int] = None, max_block: Optional[int] = None) -> int:
+        """Allocate the step workspace for the longest context expected (default: every patch), so that no step of a run
+        pays for a reallocation when the sampled context grows.  Returns the bytes held."""
+        k = int(max_context) if max_context is not None else self.num_patches
+        nblk = int(num_blocks) if num_blocks is not None else self.num_target_blocks
+        m = int(max_block) if max_block is not None else self.num_patches
+        need = max(lib.mae_engine_jepa_workspace_bytes(self.net.engine.handle, batch, kk, nblk, m) for kk in {k, max(1, k // 2)})
+        if need < 0:
+            raise ValueError(f"bad I-JEPA token counts (batch {batch}, context {k}, {nblk} blocks of {m})")
+        dev = self._require_cuda()
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        return int(self._workspace.numel())
+
     # ---- masks ---------------------------------------------------------------------------------------------------------------
     def sample_masks(self, batch: int, gen: torch.Generator) -> Tuple[torch.Tensor, torch.Tensor]:
         return sample_block_masks(batch, self.grid, gen, self.num_target_blocks, self.target_scale, self.target_aspect, self.context_scale)

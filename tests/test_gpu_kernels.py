@@ -233,7 +233,8 @@ def test_linear_fwd_gelu_grad_many_tiles(dev, M, N, K, has_bias):
     assert (out.double() - slope_ref).abs().max() < 0.05 and (out2.double() - act_ref).abs().max() < 0.08
 
 
-@pytest.mark.parametrize("M,N,K", [(70, 144, 192), (5000, 432, 144), (4100, 192, 768), (9000, 384, 384), (300, 16, 32), (8200, 1536, 384), (6000, 384, 1536), (4289, 576, 192), (20000, 1152, 384), (4096, 192, 192)])
+@pytest.mark.parametrize("M,N,K", [(70, 144, 192), (5000, 432, 144), (4100, 192, 768), (9000, 384, 384), (300, 16, 32), (8200, 1536, 384), (6000, 384, 1536), (4289, 576, 192), (20000, 1152, 384), (4096, 192, 192),
+                                   (5000, 512, 1024), (4500, 1024, 512), (4200, 1536, 512), (4100, 328, 200)])  # + widths with a partial last 192-tile column
 @pytest.mark.parametrize("dt", [F32, BF16])
 def test_linear_wgrad(dev, M, N, K, dt):
     g = G(M + N + K)
@@ -296,7 +297,7 @@ g = torch.Generator(device=dev).manual_seed(11)
 MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5, "gelu_act": 6}
 out = {}
 # (M, N, K): full tiles, a ragged last tile, several tiles per CU, nk = 3 / 6 / 24, N multiples of 192 and of 128
-for M, N, K in [(70000, 1536, 384), (4099, 384, 192), (33000, 1152, 384), (9000, 384, 1536), (20000, 512, 256), (300, 192, 192)]:
+for M, N, K in [(70000, 1536, 384), (4099, 384, 192), (33000, 1152, 384), (9000, 384, 1536), (20000, 512, 256), (300, 192, 192), (9000, 512, 1024)]:
     A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
     W = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
     bias = torch.rand(N, device=dev, generator=g)

@@ -41,6 +41,9 @@ WGRAD_SHAPES = [  # name, M, N, K   (dW[N,K] = dY[M,N]^T A[M,K], db = colsum dY)
     ("enc fc2 wgrad", 72000, 384, 1536), ("dec qkv wgrad", 290000, 576, 192), ("dec proj wgrad", 290000, 192, 192),
     ("dec fc1 wgrad", 290000, 768, 192), ("dec fc2 wgrad", 290000, 192, 768), ("patch wgrad", 70000, 384, 192),
     ("dec embed wgrad", 72000, 192, 384), ("pred wgrad", 218000, 192, 192),
+    # widths that are not multiples of 192 (ViT-L/14, the 512-wide decoder of configs[3]; ViT-B/16 for comparison)
+    ("vitl qkv wgrad", 65536, 3072, 1024), ("vitl proj wgrad", 65536, 1024, 1024), ("vitl fc1 wgrad", 65536, 4096, 1024),
+    ("dec512 qkv wgrad", 100864, 1536, 512), ("dec512 fc2 wgrad", 100864, 512, 2048), ("vitb fc1 wgrad", 25088, 3072, 768),
 ]
 MODE = {"none": 0, "gelu": 1, "resid": 2, "dgelu": 3, "gelu_grad": 4, "mul": 5, "gelu_act": 6}
 
