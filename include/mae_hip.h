@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MAE_ABI_VERSION 2
+#define MAE_ABI_VERSION 3
 
 enum { MAE_F32 = 0, MAE_BF16 = 1, MAE_U8 = 2 /* images only */ };
 
@@ -119,6 +119,15 @@ int mae_engine_forward_decoder(mae_engine_t* e, const float* params, const void*
 int mae_patchify_gather(const void* images, int32_t image_dtype, const int64_t* idx_mask, int32_t batch,
                         int32_t in_chans, int32_t image_size, int32_t patch_size, int32_t num_mask, float* target,
                         void* stream);
+
+/* The augmentation step in front of the path: transforms.RandomResizedCrop(96, scale=(0.8, 1.0)) +
+ * RandomHorizontalFlip() on the uint8 image, before ToTensor (src/data.py:15-20).  params (batch, 5)
+ * int32 = (top, left, height, width, flip) per image, drawn by the caller (torchvision's get_params
+ * rule, ssrl_vit_mae_jepa_amd/data.py); the box is resampled bilinearly to image_size x image_size
+ * (pixel centres aligned, border clamp), rounded to uint8, columns mirrored when flip != 0.
+ * images, out (batch, C, S, S) uint8, out != images. */
+int mae_augment_crop_flip_u8(const uint8_t* images, const int32_t* params, int32_t batch, int32_t in_chans,
+                             int32_t image_size, uint8_t* out, void* stream);
 
 /* torch.nn.MSELoss() (src/training/mae.py:40,48) over n elements, and its gradient w.r.t. pred
  * scaled by grad_scale: loss[0] = mean((pred-target)^2); d_pred = grad_scale*2*(pred-target)/n.

@@ -18,7 +18,7 @@ MAE_F32, MAE_BF16, MAE_U8 = 0, 1, 2
 PARAM_TRAINABLE, PARAM_FROZEN, PARAM_UNUSED, PARAM_MATRIX = 1, 2, 4, 8
 LOSS_MSE, LOSS_SMOOTH_L1 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL, EPI_GELU_ACT = 0, 1, 2, 3, 4, 5, 6
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class MaeConfig(C.Structure):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "mae_engine_forward_encoder": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mae_engine_forward_decoder": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mae_patchify_gather": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "mae_augment_crop_flip_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "mae_mse_loss": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp]),
     "mae_engine_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp]),
     "mae_engine_loss_and_grads": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),

@@ -241,4 +241,56 @@ int launch_patchify_gather_u8_i64(const uint8_t* images, const int64_t* mask64, 
   return launch_patchify_u8(images, mask64, B, m, C, img, p, target, s);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The augmentation step in front of the path (src/data.py:15-20: RandomResizedCrop(size, scale=(0.8, 1.0)) +
+// RandomHorizontalFlip on the PIL uint8 image, before ToTensor): per image a crop box (top, left, h, w) and a flip flag are
+// drawn on the host side (ssrl_vit_mae_jepa_amd/data.py: random_resized_crop_params) and this kernel resamples the box to
+// the full size x size frame, bilinear, pixel centres aligned as F.grid_sample(align_corners=False, padding_mode="border")
+// does, rounds to uint8 like the PIL resize and mirrors columns when flip is set.  uint8 in, uint8 out: the batch stays
+// 1 B per pixel all the way into the engine's pixel readers.  One thread per output pixel, all channels.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) augment_crop_flip_u8_kernel(const uint8_t* __restrict__ in, const int32_t* __restrict__ params,
+                                                                   int B, int C, int S, uint8_t* __restrict__ out) {
+  const int64_t total = (int64_t)B * S * S;
+  const float inv2s = 0.5f / (float)S;
+  for (int64_t u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int b = (int)(u / (S * S));
+    const int r = (int)(u - (int64_t)b * S * S);
+    const int oy = r / S, ox = r - oy * S;
+    const int top = params[5 * b + 0], left = params[5 * b + 1], h = params[5 * b + 2], w = params[5 * b + 3], flip = params[5 * b + 4];
+    // source coordinate of the output pixel centre: left + w * (2 ox' + 1) / (2 S) - 0.5, ox' mirrored under a flip
+    const int oxm = flip ? S - 1 - ox : ox;
+    float fx = (float)left + (float)w * (float)(2 * oxm + 1) * inv2s - 0.5f;
+    float fy = (float)top + (float)h * (float)(2 * oy + 1) * inv2s - 0.5f;
+    fx = fminf(fmaxf(fx, 0.f), (float)(S - 1));   // border padding: coordinates are clipped before interpolation
+    fy = fminf(fmaxf(fy, 0.f), (float)(S - 1));
+    const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+    const int x1 = x0 + 1 < S ? x0 + 1 : S - 1, y1 = y0 + 1 < S ? y0 + 1 : S - 1;
+    const float ax = fx - (float)x0, ay = fy - (float)y0;
+    const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
+    const uint8_t* src = in + (int64_t)b * C * S * S;
+    uint8_t* dst = out + (int64_t)b * C * S * S + oy * S + ox;
+    for (int c = 0; c < C; ++c) {
+      const uint8_t* pc = src + (int64_t)c * S * S;
+      const float v = w00 * (float)pc[y0 * S + x0] + w01 * (float)pc[y0 * S + x1] + w10 * (float)pc[y1 * S + x0] + w11 * (float)pc[y1 * S + x1];
+      dst[(int64_t)c * S * S] = (uint8_t)(int)fminf(fmaxf(rintf(v), 0.f), 255.f);
+    }
+  }
+}
+
+int launch_augment_crop_flip_u8(const uint8_t* in, const int32_t* params, int B, int C, int S, uint8_t* out, hipStream_t s) {
+  MAE_REQUIRE(in && params && out && B > 0 && C > 0 && S > 0, "augment_crop_flip_u8: bad arguments");
+  MAE_REQUIRE(in != out, "augment_crop_flip_u8: in-place resampling is not supported");
+  const int grid = (int)std::min<int64_t>(cdiv((int64_t)B * S * S, 256), 256 * 32);
+  hipLaunchKernelGGL(augment_crop_flip_u8_kernel, dim3(grid), dim3(256), 0, s, in, params, B, C, S, out);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace mae
+
+extern "C" int mae_augment_crop_flip_u8(const uint8_t* images, const int32_t* params, int32_t batch, int32_t in_chans, int32_t image_size,
+                                        uint8_t* out, void* stream) {
+  return mae::launch_augment_crop_flip_u8(images, params, batch, in_chans, image_size, out, (hipStream_t)stream);
+}

@@ -53,6 +53,7 @@ int launch_mse_from_images_u8(const float* pred, const uint8_t* images, const in
                               float grad_scale, float* loss, void* d_pred, int dpred_dt, float* scratch, hipStream_t s);
 int launch_patchify_gather_u8(const uint8_t* images, const int32_t* mask32, int B, int m, int C, int img, int p, float* target, hipStream_t s);
 int launch_patchify_gather_u8_i64(const uint8_t* images, const int64_t* mask64, int B, int m, int C, int img, int p, float* target, hipStream_t s);
+int launch_augment_crop_flip_u8(const uint8_t* in, const int32_t* params, int B, int C, int S, uint8_t* out, hipStream_t s);
 int launch_cast(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, hipStream_t s);
 // out[r] = x[r] + pos[r mod L] (fp32 rows of D)
 int launch_add_rows_pos(const float* x, const float* pos, int64_t rows, int L, int D, float* out, hipStream_t s);

@@ -85,6 +85,24 @@ def augment_batch(x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
     return F.grid_sample(x, grid, mode="bilinear", padding_mode="border", align_corners=False)
 
 
+def augment_batch_u8(x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
+    """The same augmentation on a uint8 device batch, by the HIP kernel behind ``mae_augment_crop_flip_u8`` (uint8 in, uint8
+    out, as the reference's PIL transforms run before ToTensor): the crop boxes and flips are drawn here with the rule of
+    ``random_resized_crop_params``, the resampling runs in libmae_hip.so.  No torch fallback: a missing extension fails loudly."""
+    from ._lib import check, lib, ptr
+    from .mae import _stream
+    if x.dtype != torch.uint8 or not x.is_cuda or x.dim() != 4 or x.shape[2] != x.shape[3]:
+        raise ValueError(f"augment_batch_u8 needs a square (B, C, S, S) uint8 CUDA batch, got {tuple(x.shape)} {x.dtype} on {x.device}")
+    B, C, S, _ = x.shape
+    top, left, h, w = random_resized_crop_params(B, S, gen)
+    flip = torch.rand(B, generator=gen, device=gen.device) < 0.5
+    params = torch.stack([top, left, h, w, flip.to(torch.int64)], dim=1).to(device=x.device, dtype=torch.int32).contiguous()
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(lib.mae_augment_crop_flip_u8(ptr(x), ptr(params), B, C, S, ptr(out), _stream(x.device)))
+    return out
+
+
 class PinnedBatchStream:
     """uint8 dataset in pinned host memory -> device batches through two device buffers (double buffering).
 
@@ -173,7 +191,9 @@ def get_pretrain_batches(cfg: dict, device: torch.device, synthetic_images: Opti
     def finish(x: torch.Tensor) -> torch.Tensor:
         if not augment:
             return x.contiguous()  # uint8 stays uint8: normalised inside the engine
-        x = normalize_u8(x) if x.dtype == torch.uint8 else x  # the resampling needs floats
+        if x.dtype == torch.uint8 and x.is_cuda:
+            return augment_batch_u8(x, aug_gen)  # HIP resampler: uint8 in, uint8 out, normalised inside the engine
+        x = normalize_u8(x) if x.dtype == torch.uint8 else x  # synthetic float batches / host tensors: torch resampling
         return augment_batch(x, aug_gen).contiguous()
 
     def serve(order: torch.Tensor) -> Iterator[torch.Tensor]:

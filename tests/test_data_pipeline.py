@@ -105,3 +105,60 @@ def test_pinned_double_buffered_stream_serves_the_right_batches(dev):
         assert [t[0].shape[0] for t in got] == [8, 8, 8, 8, 5]
         assert torch.equal(torch.cat([t[0] for t in got]).cpu(), data[order])
         assert torch.equal(torch.cat([t[1] for t in got]).cpu(), data[order].float().sum(dim=(1, 2, 3)))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# augmentation in front of the path: RandomResizedCrop + RandomHorizontalFlip on uint8, the HIP resampler behind
+# mae_augment_crop_flip_u8 against the torch restatement (affine_grid + grid_sample, align_corners=False, border)
+# ----------------------------------------------------------------------------------------------------------------------
+def _resample_reference(u8, params):
+    """The crop boxes of `params` resampled with the torch ops augment_batch uses, on the raw 0..255 values, rounded to uint8."""
+    import torch.nn.functional as F
+    B, _, S, _ = u8.shape
+    top, left, h, w, flip = (params[:, i].to(torch.float32) for i in range(5))
+    sx = torch.where(flip > 0, -w / S, w / S); sy = h / S
+    theta = torch.zeros(B, 2, 3)
+    theta[:, 0, 0] = sx; theta[:, 0, 2] = (2.0 * left + w) / S - 1.0
+    theta[:, 1, 1] = sy; theta[:, 1, 2] = (2.0 * top + h) / S - 1.0
+    grid = F.affine_grid(theta, list(u8.shape), align_corners=False)
+    out = F.grid_sample(u8.to(torch.float32), grid, mode="bilinear", padding_mode="border", align_corners=False)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,S", [(7, 3, 96), (3, 1, 32), (33, 3, 224)])
+def test_hip_crop_resize_flip_matches_the_torch_restatement(dev, B, C, S):
+    from ssrl_vit_mae_jepa_amd._lib import check, lib, ptr
+    from ssrl_vit_mae_jepa_amd.mae import _stream
+    g = torch.Generator().manual_seed(B + S)
+    u8 = torch.randint(0, 256, (B, C, S, S), generator=g, dtype=torch.uint8)
+    top, left, h, w = D.random_resized_crop_params(B, S, g)
+    flip = (torch.rand(B, generator=g) < 0.5).to(torch.int64)
+    params = torch.stack([top, left, h, w, flip], 1).to(torch.int32)
+    params[0] = torch.tensor([0, 0, S, S, 0])      # identity box: the image itself
+    params[1] = torch.tensor([0, 0, S, S, 1])      # identity box, mirrored
+    ref = _resample_reference(u8, params)
+    xd, pd = u8.to(dev), params.to(dev)
+    out = torch.empty_like(xd)
+    check(lib.mae_augment_crop_flip_u8(ptr(xd), ptr(pd), B, C, S, ptr(out), _stream(dev)))
+    out = out.cpu()
+    assert torch.equal(out[0], u8[0]) and torch.equal(out[1], u8[1].flip(-1))
+    # bilinear weights are computed in a different order than affine_grid + grid_sample: the fp32 value can land on the other
+    # side of a .5 rounding boundary for a few pixels; never more than one grey level
+    diff = (out.to(torch.float32) - ref.round().clamp(0, 255)).abs()
+    assert diff.max() <= 1 and (diff > 0).float().mean() < 1e-2   # random-noise images: every pixel sits on a steep gradient
+    assert (out.to(torch.float32) - ref).abs().max() <= 0.5 + 1e-2
+
+
+@pytest.mark.gpu
+def test_augmented_uint8_batches_reach_the_engine_as_uint8(dev):
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randint(0, 256, (16, 3, 96, 96), generator=g, dtype=torch.uint8, device=dev)
+    y = D.augment_batch_u8(x, torch.Generator(device=dev).manual_seed(9))
+    y2 = D.augment_batch_u8(x, torch.Generator(device=dev).manual_seed(9))
+    assert y.dtype == torch.uint8 and y.shape == x.shape and torch.equal(y, y2) and not torch.equal(y, x)
+    # same boxes and flips as the float path draws from the same generator state
+    z = D.augment_batch(D.normalize_u8(x.cpu()).to(dev), torch.Generator(device=dev).manual_seed(9))
+    assert (D.normalize_u8(y.cpu()).to(dev) - z).abs().max() <= (0.5 + 1e-2) / 127.5
+    with pytest.raises(ValueError):
+        D.augment_batch_u8(x.float(), torch.Generator(device=dev).manual_seed(9))
