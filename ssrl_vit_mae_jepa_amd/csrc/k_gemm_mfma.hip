@@ -418,7 +418,9 @@ __device__ __forceinline__ void tn_glds16(const bf16* src, char* dst) {
 // tn_wait_vm<> + barrier below are what orders it against the reads, checked against the all-drained build
 // (MAE_DBG_VMCNT0) like the NT kernel's.  m0 is written behind the compiler's back: nothing else in these kernels uses it.
 __device__ __forceinline__ void tn_glds16_raw(const bf16* src, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory");
+  // (s_nop 0: an SALU write of m0 needs one wait state before an LDS-DMA reads it; hipcc's hazard recognizer, which inserts
+  //  it for the builtin, does not look inside inline asm)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory");
 }
 template <bool RAW>
 __device__ __forceinline__ void tn_dma(const bf16* src, char* dst) {
