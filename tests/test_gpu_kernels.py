@@ -89,7 +89,7 @@ def test_mse_loss(dev, n):
 
 
 # ----------------------------------------------------------------------------------------------- layernorm
-@pytest.mark.parametrize("rows,dim", [(5, 144), (72, 192), (1000, 384), (33, 768), (9, 1024), (4, 8)])
+@pytest.mark.parametrize("rows,dim", [(5, 144), (72, 192), (1000, 384), (33, 768), (9, 1024), (4, 8), (1001, 384), (7, 48), (70001, 192)])  # 16 / 32 / 64 lanes per row, row counts that leave a lane group without a row
 @pytest.mark.parametrize("dt", [F32, BF16])
 def test_layernorm_fwd_bwd(dev, rows, dim, dt):
     g = G(rows + dim)
