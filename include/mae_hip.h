@@ -281,6 +281,15 @@ int64_t mae_linear_wgrad_scratch_bytes(int64_t M, int32_t N, int32_t K);
 int mae_linear_wgrad(const void* dY, const void* A, int64_t M, int32_t N, int32_t K, int32_t dtype, float* dW,
                      float* db, void* scratch, void* stream);
 
+/* Two weight gradients over the same M rows in one launch (the engine pairs a block's fc2 + fc1 and proj + qkv:
+ * torch.autograd's dW = dY^T X of two nn.Linear, timm Block / Attention).  Same results contract as two
+ * mae_linear_wgrad calls (fp32 dW / db written); falls back to exactly those when a shape is outside the
+ * ring kernel.  scratch >= mae_linear_wgrad_pair_scratch_bytes. */
+int64_t mae_linear_wgrad_pair_scratch_bytes(int64_t M, int32_t N0, int32_t K0, int32_t N1, int32_t K1);
+int mae_linear_wgrad_pair(const void* dY0, const void* A0, int32_t N0, int32_t K0, float* dW0, float* db0,
+                          const void* dY1, const void* A1, int32_t N1, int32_t K1, float* dW1, float* db1,
+                          int64_t M, int32_t dtype, void* scratch, void* stream);
+
 /* Multi-head self-attention core of timm Attention (F.scaled_dot_product_attention, no mask, no dropout).
  * qkv: (batch, T, 3, H, hd) in `dtype` as the qkv Linear emits it; out: (batch, T, H*hd) in `dtype`;
  * lse: (batch, H, T) fp32 log-sum-exp of the scaled scores, saved for backward. */

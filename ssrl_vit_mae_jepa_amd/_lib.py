@@ -89,6 +89,8 @@ SIGNATURES = {
     "mae_linear_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "mae_linear_wgrad_scratch_bytes": (_i64, [_i64, _i32, _i32]),
     "mae_linear_wgrad": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "mae_linear_wgrad_pair_scratch_bytes": (C.c_int64, [_i64, _i32, _i32, _i32, _i32]),
+    "mae_linear_wgrad_pair": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _vp]),
     "mae_attention_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "mae_attention_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
 }

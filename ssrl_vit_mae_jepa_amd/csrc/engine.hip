@@ -195,6 +195,11 @@ static Plan make_plan_ex(const mae_engine* e, int B, int k, int dec_B, int dec_T
   wgs(pl.Me, 3 * e->D, e->D); wgs(pl.Me, e->mlp * e->D, e->D); wgs(pl.Me, e->D, e->mlp * e->D); wgs(pl.Me, e->D, e->D);
   wgs(pl.Md, 3 * e->Dd, e->Dd); wgs(pl.Md, e->mlp * e->Dd, e->Dd); wgs(pl.Md, e->Dd, e->mlp * e->Dd); wgs(pl.Md, e->Dd, e->Dd);
   wgs(pl.Me, e->D, e->P); wgs(pl.Me, e->Dd, e->D); wgs(std::max<int64_t>(pl.Mp, 1), e->PO, e->Dd);
+  auto wgp = [&](int64_t M, int d) {  // the paired launches of a block: fc2 + fc1, proj + qkv
+    wg = std::max(wg, linear_wgrad_pair_scratch_bytes(M, d, e->mlp * d, e->mlp * d, d));
+    wg = std::max(wg, linear_wgrad_pair_scratch_bytes(M, d, d, 3 * d, d));
+  };
+  wgp(pl.Me, e->D); wgp(pl.Md, e->Dd);
   pl.wgrad_scratch = take(wg);
   pl.loss_scratch = take(4096 * 4);
   pl.total = off;
@@ -329,6 +334,17 @@ static int wgrad(const Ctx& c, const Plan& pl, const void* dY, const void* A, in
   return 0;
 }
 
+// two weight gradients over the same rows in one launch (k_gemm.hip: launch_linear_wgrad_pair); main stream only
+static int wgrad_pair(const Ctx& c, const Plan& pl, int64_t M, const void* dY0, const void* A0, int N0, int K0, int w0, int b0,
+                      const void* dY1, const void* A1, int N1, int K1, int w1, int b1) {
+  mae_engine* e = c.e;
+  hipStream_t s = c.s;
+  RUN(TK_WGRAD, 2.0 * M * ((double)N0 * K0 + (double)N1 * K1),
+      (double)(M * (int64_t)(N0 + K0 + N1 + K1) * c.as + ((int64_t)N0 * K0 + (int64_t)N1 * K1) * 4),
+      launch_linear_wgrad_pair(dY0, A0, N0, K0, c.Gp(w0), c.Gp(b0), dY1, A1, N1, K1, c.Gp(w1), c.Gp(b1), M, c.act, c.buf<>(pl.wgrad_scratch), s));
+  return 0;
+}
+
 // join: everything on the side stream is finished before the main stream continues
 static int join_side(const Ctx& c) {
   mae_engine* e = c.e;
@@ -377,7 +393,21 @@ static int block_backward(const Ctx& c, const Plan& pl, const BlockRefs& r, cons
   const int hd = d / heads, hid = e->mlp * d;
   float* dres = c.buf<float>(pl.dres);
   void* dres_c = c.buf<>(pl.dres_c);
-  // MLP branch
+  if (!side_enabled(e)) {
+    // Each branch's two weight gradients go out as ONE launch, placed where both of their dY operands exist and before the
+    // LayerNorm backward that rewrites dres_c (fc2 / proj read it).  Same dependencies as the separate launches below.
+    MAE_TRY(dgrad(c, dres_c, r.fc2_w, M, d, hid, MAE_EPI_MUL, c.buf<>(pl.d_hidden), c.buf<>(b.fc1_pre)));
+    MAE_TRY(wgrad_pair(c, pl, M, dres_c, c.buf<>(b.fc1_act), d, hid, r.fc2_w, r.fc2_b, c.buf<>(pl.d_hidden), c.buf<>(b.ln2), hid, d, r.fc1_w, r.fc1_b));
+    MAE_TRY(dgrad(c, c.buf<>(pl.d_hidden), r.fc1_w, M, hid, d, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
+    RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(b.x_mid), nullptr, c.P(r.ln2_w), c.buf<float>(b.mean2), c.buf<float>(b.rstd2), M, d, 1, dres, dres_c, c.Gp(r.ln2_w), c.Gp(r.ln2_b), ln_slot(c, pl), s, &e->ln_tab));
+    MAE_TRY(dgrad(c, dres_c, r.proj_w, M, d, d, MAE_EPI_NONE, c.buf<>(pl.d_att), nullptr));
+    RUN(TK_ATTN_BWD, 10.0 * Bn * heads * (double)T * T * hd, M * 9 * d * c.as, launch_attention_bwd(c.buf<>(b.qkv), c.buf<>(b.att), c.buf<>(pl.d_att), c.buf<float>(b.lse), Bn, T, heads, hd, c.act, c.buf<>(pl.d_qkv), s));
+    MAE_TRY(wgrad_pair(c, pl, M, dres_c, c.buf<>(b.att), d, d, r.proj_w, r.proj_b, c.buf<>(pl.d_qkv), c.buf<>(b.ln1), 3 * d, d, r.qkv_w, r.qkv_b));
+    MAE_TRY(dgrad(c, c.buf<>(pl.d_qkv), r.qkv_w, M, 3 * d, d, MAE_EPI_NONE, c.buf<>(pl.d_ln), nullptr));
+    RUN(TK_LN_BWD, 0, M * d * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_ln), c.act, c.buf<float>(x_in), nullptr, c.P(r.ln1_w), c.buf<float>(b.mean1), c.buf<float>(b.rstd1), M, d, 1, dres, dres_c, c.Gp(r.ln1_w), c.Gp(r.ln1_b), ln_slot(c, pl), s, &e->ln_tab));
+    return 0;
+  }
+  // MLP branch (weight gradients on the side stream, MAE_WGRAD_STREAM=1: separate launches)
   MAE_TRY(wgrad(c, pl, dres_c, c.buf<>(b.fc1_act), M, d, hid, r.fc2_w, r.fc2_b, DEP_DRESC));
   MAE_TRY(await_side(e, DEP_HIDDEN, s));  // the previous block's fc1 wgrad reads d_hidden
   MAE_TRY(dgrad(c, dres_c, r.fc2_w, M, d, hid, MAE_EPI_MUL, c.buf<>(pl.d_hidden), c.buf<>(b.fc1_pre)));

@@ -19,6 +19,12 @@ int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K);
 // also db[N] = column sums of dY when db != null
 int mfma_linear_wgrad(const bf16* dY, const bf16* A, int64_t M, int N, int K, float* dW, float* db, void* slab, hipStream_t s);
 
+// two weight gradients that share M in one launch (one tile list, M-splits chosen for the sum); MFMA_UNSUPPORTED when either
+// shape is not one of the 192 x 192 ring kernel's, M < 8192, a bias gradient is missing, or an A/B switch is set
+int64_t mfma_wgrad_pair_scratch_bytes(int64_t M, int N0, int K0, int N1, int K1);
+int mfma_linear_wgrad_pair(const bf16* dY0, const bf16* A0, int N0, int K0, float* dW0, float* db0, const bf16* dY1, const bf16* A1,
+                           int N1, int K1, float* dW1, float* db1, int64_t M, void* slab, hipStream_t s);
+
 // attention (k_attention_mfma.hip)
 int mfma_attention_fwd(const bf16* qkv, int B, int T, int H, int hd, bf16* out, float* lse, hipStream_t s);
 int mfma_attention_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int H, int hd,

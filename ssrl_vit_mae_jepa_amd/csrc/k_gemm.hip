@@ -188,6 +188,24 @@ int64_t linear_wgrad_scratch_bytes(int64_t M, int N, int K) {
   return round_up((int64_t)COLSUM_BLOCKS * N * 4, 256) + mfma_wgrad_scratch_bytes(M, N, K);
 }
 
+// Two weight gradients over the same M rows (a block's fc2 + fc1, or proj + qkv): one launch when both shapes belong to the
+// ring kernel (bf16 operands), otherwise two ordinary calls.  scratch: >= linear_wgrad_pair_scratch_bytes.
+int64_t linear_wgrad_pair_scratch_bytes(int64_t M, int N0, int K0, int N1, int K1) {
+  return std::max(std::max(linear_wgrad_scratch_bytes(M, N0, K0), linear_wgrad_scratch_bytes(M, N1, K1)),
+                  mfma_wgrad_pair_scratch_bytes(M, N0, K0, N1, K1));
+}
+int launch_linear_wgrad_pair(const void* dY0, const void* A0, int N0, int K0, float* dW0, float* db0, const void* dY1, const void* A1,
+                             int N1, int K1, float* dW1, float* db1, int64_t M, int dt, void* scratch, hipStream_t s) {
+  MAE_REQUIRE(dY0 && A0 && dW0 && dY1 && A1 && dW1 && M > 0, "linear_wgrad_pair: bad arguments");
+  if (dt == MAE_BF16 && scratch) {
+    const int r = mfma_linear_wgrad_pair((const bf16*)dY0, (const bf16*)A0, N0, K0, dW0, db0, (const bf16*)dY1, (const bf16*)A1, N1, K1, dW1,
+                                         db1, M, scratch, s);
+    if (r != MFMA_UNSUPPORTED) return r;
+  }
+  MAE_TRY(launch_linear_wgrad(dY0, A0, M, N0, K0, dt, dW0, db0, scratch, s));
+  return launch_linear_wgrad(dY1, A1, M, N1, K1, dt, dW1, db1, scratch, s);
+}
+
 int launch_linear_wgrad(const void* dY, const void* A, int64_t M, int N, int K, int dt, float* dW, float* db, void* scratch,
                         hipStream_t s) {
   MAE_REQUIRE(dY && A && dW && M > 0 && N > 0 && K > 0, "linear_wgrad: bad arguments");
@@ -238,6 +256,14 @@ extern "C" int mae_linear_fwd(const void* A, const void* W, const float* bias, i
   return mae::launch_linear_fwd(A, W, M, N, K, dtype, e, (hipStream_t)stream);
 }
 
+extern "C" int64_t mae_linear_wgrad_pair_scratch_bytes(int64_t M, int32_t N0, int32_t K0, int32_t N1, int32_t K1) {
+  return mae::linear_wgrad_pair_scratch_bytes(M, N0, K0, N1, K1);
+}
+extern "C" int mae_linear_wgrad_pair(const void* dY0, const void* A0, int32_t N0, int32_t K0, float* dW0, float* db0, const void* dY1,
+                                     const void* A1, int32_t N1, int32_t K1, float* dW1, float* db1, int64_t M, int32_t dtype,
+                                     void* scratch, void* stream) {
+  return mae::launch_linear_wgrad_pair(dY0, A0, N0, K0, dW0, db0, dY1, A1, N1, K1, dW1, db1, M, dtype, scratch, (hipStream_t)stream);
+}
 extern "C" int64_t mae_linear_wgrad_scratch_bytes(int64_t M, int32_t N, int32_t K) {
   return mae::linear_wgrad_scratch_bytes(M, N, K);
 }

@@ -624,17 +624,37 @@ __global__ void __launch_bounds__(512, 2) gemm_tn2_kernel(const bf16* __restrict
 //               reads (st, rows 32-63) interleaved 1:1 with the MFMAs of (st,   rows 0-31)
 // Every accumulator sees the same products in the same order as in v2, so the two kernels agree bit for bit.
 // ---------------------------------------------------------------------------------------------------
+// One launch can serve TWO weight gradients that share their row count M (the engine pairs fc2 + fc1 and proj + qkv of a
+// block): the tiles of both problems form one list, so the M-splits are chosen for the sum.  Alone, the 384 x 384 proj gradient
+// needs 64 splits of 18 steps to fill the chip (38 MB of fp32 partials for a 0.6 MB result, 0.47 PF/s); next to qkv it takes
+// 16 splits of 70 steps.  `out` / `db` point at the problem's slot inside split 0 of the slab (or at dW / db when there is one
+// split); the kernel adds split * split_stride.
+struct TnProb {
+  const bf16* dY; const bf16* X; float* out; float* db;
+  int N, K, tiles_k, tile_begin;
+};
+struct TnGroup {
+  TnProb p[2];
+  int nprob, total_tiles;
+};
+
 template <bool RAW>
-__global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(const bf16* __restrict__ dY, const bf16* __restrict__ X, int64_t M, int N, int K,
-                                                          float* __restrict__ out, float* __restrict__ db, int64_t split_stride,
-                                                          int tiles_n, int tiles_k, int64_t m_chunk) {
+__global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(TnGroup grp, int64_t M, int64_t split_stride, int64_t m_chunk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
   const int vb = (int)xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = vb % (tiles_n * tiles_k);
-  const int split = vb / (tiles_n * tiles_k);
+  const int gtile = vb % grp.total_tiles;
+  const int split = vb / grp.total_tiles;
+  const bool second = grp.nprob > 1 && gtile >= grp.p[1].tile_begin;   // workgroup-uniform
+  const bf16* __restrict__ dY = second ? grp.p[1].dY : grp.p[0].dY;
+  const bf16* __restrict__ X = second ? grp.p[1].X : grp.p[0].X;
+  float* __restrict__ out = second ? grp.p[1].out : grp.p[0].out;
+  float* __restrict__ db = second ? grp.p[1].db : grp.p[0].db;
+  const int N = second ? grp.p[1].N : grp.p[0].N, K = second ? grp.p[1].K : grp.p[0].K;
+  const int tiles_k = second ? grp.p[1].tiles_k : grp.p[0].tiles_k;
+  const int tile = gtile - (second ? grp.p[1].tile_begin : 0);
   const int n0 = (tile / tiles_k) * T2, k0 = (tile % tiles_k) * T2;
   const int64_t mbeg = (int64_t)split * m_chunk;
   const int64_t mend = mbeg + m_chunk < M ? mbeg + m_chunk : M;
@@ -905,6 +925,32 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
   }
 }
 
+// the same ordered sum for the slabs of a pair launch: up to four output segments (dW0, db0, dW1, db1) laid out back to back
+// inside every split's slab, in float4 units
+struct SlabSegs { int64_t end4[4]; float* dst[4]; };
+__global__ void __launch_bounds__(256) slab_reduce_group_kernel(const float* __restrict__ slabs, int S, int64_t stride4, SlabSegs sg) {
+  __shared__ f32x4 red[8][32];
+  const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t total = sg.end4[3];
+  for (int64_t base = blockIdx.x * 32ll; base < total; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + o;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (i < total)
+      for (int s = sl; s < S; s += 8) acc += load4(slabs + ((int64_t)s * stride4 + i) * 4);
+    red[sl][o] = acc;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      f32x4 t = red[0][o];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) t += red[k][o];
+      const int seg = i < sg.end4[0] ? 0 : (i < sg.end4[1] ? 1 : (i < sg.end4[2] ? 2 : 3));
+      const int64_t b4 = seg == 0 ? 0 : sg.end4[seg - 1];
+      store4(sg.dst[seg] + (i - b4) * 4, t);
+    }
+    __syncthreads();
+  }
+}
+
 static int wgrad_splits(int64_t M, int N, int K) {
   const int tn = N % 128 == 0 || N % 64 != 0 ? 128 : 64, tk = K % 128 == 0 || K % 64 != 0 ? 128 : 64;  // ragged dims take 128-wide tiles
   const int64_t tiles = (int64_t)cdiv(N, tn) * cdiv(K, tk);
@@ -950,9 +996,18 @@ int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, fl
     const char* ev = getenv("MAE_WGRAD");  // A/B switch (tools/gemm_bench.py --wgrad): v2 | v2r | v3 | v3r (default); r = DMA issued from inline asm
     const bool sel = ev && ev[0] == 'v' && (ev[1] == '2' || ev[1] == '3');
     const bool k3 = !sel || ev[1] == '3', raw = !sel || ev[2] == 'r';
-    auto kern = k3 ? (raw ? gemm_tn3_kernel<true> : gemm_tn3_kernel<false>) : (raw ? gemm_tn2_kernel<true> : gemm_tn2_kernel<false>);
-    MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(512), lds, s, dY, X, M, N, K, out, dbo, stride, tiles_n, tiles_k, m_chunk);
+    if (k3) {
+      TnGroup g{};
+      g.p[0] = TnProb{dY, X, out, dbo, N, K, tiles_k, 0};
+      g.nprob = 1; g.total_tiles = tiles_n * tiles_k;
+      auto kern = raw ? gemm_tn3_kernel<true> : gemm_tn3_kernel<false>;
+      MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(g.total_tiles * S)), dim3(512), lds, s, g, M, stride, m_chunk);
+    } else {
+      auto kern = raw ? gemm_tn2_kernel<true> : gemm_tn2_kernel<false>;
+      MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_n * tiles_k * S)), dim3(512), lds, s, dY, X, M, N, K, out, dbo, stride, tiles_n, tiles_k, m_chunk);
+    }
     MAE_LAUNCH_CHECK();
     r = 0;
   } else if (N % 64 != 0 || K % 64 != 0) {
@@ -968,6 +1023,62 @@ int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, fl
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, s, (const float*)slab, S, stride / 4, nw4, nb4, dW, db);
     MAE_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+
+// ---- two weight gradients with the same M in one launch (see TnGroup) -------------------------------------------------
+static int wgrad_pair_splits(int64_t M, int64_t tiles, int64_t nk_sum) {
+  const int64_t cus = num_cus();
+  const int64_t smax = std::min<int64_t>(512, std::max<int64_t>(1, M / 256));
+  const double t1 = (double)M / T2_BR * 1.5, slab = (double)nk_sum * 8.0 / 5.0e6;
+  int best = 2;
+  double best_cost = 1e30;
+  for (int64_t S = 2; S <= smax; ++S) {   // at least two splits: the outputs always go through the slab
+    const double cost = (double)cdiv(tiles * S, cus) * t1 / (double)S + (double)S * slab;
+    if (cost < best_cost * 0.999) { best_cost = cost; best = (int)S; }
+  }
+  return best;
+}
+static bool wgrad_pair_ok(int64_t M, int N0, int K0, int N1, int K1) {
+  const char* v = getenv("MAE_WGRAD");  // any A/B selection of a single-problem kernel, or MAE_WGRAD_PAIR=0, keeps the launches apart
+  const char* pr = getenv("MAE_WGRAD_PAIR");
+  if ((v && v[0]) || (pr && pr[0] == '0')) return false;
+  return M >= 8192 && wgrad2_shape_ok(M, N0, K0) && wgrad2_shape_ok(M, N1, K1) && N0 % 4 == 0 && N1 % 4 == 0;
+}
+int64_t mfma_wgrad_pair_scratch_bytes(int64_t M, int N0, int K0, int N1, int K1) {
+  if (M < 8192 || !wgrad2_shape_ok(M, N0, K0) || !wgrad2_shape_ok(M, N1, K1)) return 0;
+  const int64_t tiles = (int64_t)cdiv(N0, T2) * cdiv(K0, T2) + (int64_t)cdiv(N1, T2) * cdiv(K1, T2);
+  const int64_t per = (int64_t)N0 * K0 + N0 + (int64_t)N1 * K1 + N1;
+  return round_up((int64_t)wgrad_pair_splits(M, tiles, (int64_t)N0 * K0 + (int64_t)N1 * K1) * per * 4, 256);
+}
+int mfma_linear_wgrad_pair(const bf16* dY0, const bf16* X0, int N0, int K0, float* dW0, float* db0, const bf16* dY1, const bf16* X1,
+                           int N1, int K1, float* dW1, float* db1, int64_t M, void* slab, hipStream_t s) {
+  if (!wgrad_pair_ok(M, N0, K0, N1, K1) || !slab || !db0 || !db1) return MFMA_UNSUPPORTED;
+  if ((((uintptr_t)dY0 | (uintptr_t)X0 | (uintptr_t)dW0 | (uintptr_t)db0 | (uintptr_t)dY1 | (uintptr_t)X1 | (uintptr_t)dW1 | (uintptr_t)db1 |
+        (uintptr_t)slab) & 15) != 0)
+    return MFMA_UNSUPPORTED;
+  const int tn0 = (int)cdiv(N0, T2), tk0 = (int)cdiv(K0, T2), tn1 = (int)cdiv(N1, T2), tk1 = (int)cdiv(K1, T2);
+  const int64_t nk0 = (int64_t)N0 * K0, nk1 = (int64_t)N1 * K1;
+  const int S = wgrad_pair_splits(M, (int64_t)tn0 * tk0 + (int64_t)tn1 * tk1, nk0 + nk1);
+  const int64_t m_chunk = round_up(cdiv(M, S), 64);
+  const int64_t stride = nk0 + N0 + nk1 + N1;   // floats per split: [dW0 | db0 | dW1 | db1]
+  float* base = reinterpret_cast<float*>(slab);
+  TnGroup g{};
+  g.p[0] = TnProb{dY0, X0, base, base + nk0, N0, K0, tk0, 0};
+  g.p[1] = TnProb{dY1, X1, base + nk0 + N0, base + nk0 + N0 + nk1, N1, K1, tk1, tn0 * tk0};
+  g.nprob = 2; g.total_tiles = tn0 * tk0 + tn1 * tk1;
+  const int lds = T2_NSTAGE * T2_STAGE;
+  auto kern = gemm_tn3_kernel<true>;
+  MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.total_tiles * S)), dim3(512), lds, s, g, M, stride, m_chunk);
+  MAE_LAUNCH_CHECK();
+  SlabSegs sg;
+  sg.end4[0] = nk0 / 4; sg.end4[1] = sg.end4[0] + N0 / 4; sg.end4[2] = sg.end4[1] + nk1 / 4; sg.end4[3] = sg.end4[2] + N1 / 4;
+  sg.dst[0] = dW0; sg.dst[1] = db0; sg.dst[2] = dW1; sg.dst[3] = db1;
+  const int grid = (int)std::min<int64_t>(cdiv(sg.end4[3], 32), 4096);
+  hipLaunchKernelGGL(slab_reduce_group_kernel, dim3(grid), dim3(256), 0, s, (const float*)slab, S, stride / 4, sg);
+  MAE_LAUNCH_CHECK();
   return 0;
 }
 

@@ -132,6 +132,9 @@ int launch_linear_dgrad(const void* dY, const void* W, int64_t M, int N, int K, 
 int64_t linear_wgrad_scratch_bytes(int64_t M, int N, int K);
 int launch_linear_wgrad(const void* dY, const void* A, int64_t M, int N, int K, int dt, float* dW, float* db,
                         void* scratch, hipStream_t s);
+int64_t linear_wgrad_pair_scratch_bytes(int64_t M, int N0, int K0, int N1, int K1);
+int launch_linear_wgrad_pair(const void* dY0, const void* A0, int N0, int K0, float* dW0, float* db0, const void* dY1, const void* A1,
+                             int N1, int K1, float* dW1, float* db1, int64_t M, int dt, void* scratch, hipStream_t s);
 
 // ---- attention ------------------------------------------------------------------------------------------
 int launch_attention_fwd(const void* qkv, int B, int T, int H, int hd, int dt, void* out, float* lse, hipStream_t s);

@@ -247,6 +247,31 @@ def test_linear_wgrad(dev, M, N, K, dt):
     assert rel_err(db, dY.double().sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize("M,s0,s1", [(9000, (384, 1536), (1536, 384)), (8300, (384, 384), (1152, 384)), (8192, (192, 192), (576, 192)),
+                                     (9001, (512, 1024), (1536, 512)), (5000, (384, 384), (1152, 384)), (8500, (144, 144), (432, 144))])
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_linear_wgrad_pair(dev, M, s0, s1, dt):
+    """Two weight gradients over the same rows in one launch (a block's fc2 + fc1, proj + qkv) against fp64; the last three
+    cases take the fallback to two ordinary launches (ragged tile columns are fine, M < 8192 and 144-wide layers are not)."""
+    g = G(M + s0[0] + s1[1])
+    outs = []
+    args = []
+    for N, K in (s0, s1):
+        dY = torch.randn(M, N, generator=g).to(TDT[dt]); A = torch.randn(M, K, generator=g).to(TDT[dt])
+        dW = torch.full((N, K), float("nan"), device=dev); db = torch.full((N,), float("nan"), device=dev)
+        outs.append((dW, db, dY.double().t() @ A.double(), dY.double().sum(0)))
+        args.append((dv(dY), dv(A), N, K, dW, db))
+    nbytes = lib.mae_linear_wgrad_pair_scratch_bytes(M, s0[0], s0[1], s1[0], s1[1])
+    assert nbytes >= max(lib.mae_linear_wgrad_scratch_bytes(M, *s0), lib.mae_linear_wgrad_scratch_bytes(M, *s1))
+    scratch = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    (y0, a0, N0, K0, w0, b0), (y1, a1, N1, K1, w1, b1) = args
+    for rep in range(2):
+        check(lib.mae_linear_wgrad_pair(_ptr(y0), _ptr(a0), N0, K0, _ptr(w0), _ptr(b0), _ptr(y1), _ptr(a1), N1, K1, _ptr(w1), _ptr(b1),
+                                        M, dt, _ptr(scratch), stream(dev)))
+    for dW, db, ref, refb in outs:
+        assert rel_err(dW, ref) < 2e-5 and rel_err(db, refb) < 2e-5
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def _attn_ref(qkv, B, T, H, hd):
     q, k, v = qkv.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
@@ -321,6 +346,15 @@ for M, N, K in [(70000, 1536, 384), (4099, 384, 192), (33000, 1152, 384), (9000,
     for rep in range(2):
         check(lib.mae_linear_wgrad(_ptr(dY), _ptr(A), M, N, K, BF16, _ptr(dW), _ptr(db), _ptr(scratch), stream(dev)))
     out[f"tn/{M}x{N}x{K}"] = (dW.cpu(), db.cpu())
+# two weight gradients in one launch (the engine's pairing of a block's fc2 + fc1)
+M = 20000
+y0 = (torch.rand(M, 384, device=dev, generator=g) * 2 - 1).to(torch.bfloat16); a0 = (torch.rand(M, 1536, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+y1 = (torch.rand(M, 1536, device=dev, generator=g) * 2 - 1).to(torch.bfloat16); a1 = (torch.rand(M, 384, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+w0 = torch.empty(384, 1536, device=dev); b0 = torch.empty(384, device=dev); w1 = torch.empty(1536, 384, device=dev); b1 = torch.empty(1536, device=dev)
+scratch = torch.empty(lib.mae_linear_wgrad_pair_scratch_bytes(M, 384, 1536, 1536, 384), dtype=torch.uint8, device=dev)
+for rep in range(2):
+    check(lib.mae_linear_wgrad_pair(_ptr(y0), _ptr(a0), 384, 1536, _ptr(w0), _ptr(b0), _ptr(y1), _ptr(a1), 1536, 384, _ptr(w1), _ptr(b1), M, BF16, _ptr(scratch), stream(dev)))
+out["tn_pair/fc2"] = (w0.cpu(), b0.cpu()); out["tn_pair/fc1"] = (w1.cpu(), b1.cpu())
 torch.cuda.synchronize()
 torch.save(out, sys.argv[1])
 """ % str(root)
