@@ -82,15 +82,55 @@ def wgrad_main(args, dev):
     os.environ.pop("MAE_WGRAD", None)
 
 
+PAIRS = [  # name, M, (N0, K0), (N1, K1): the engine's pairings of a block's weight gradients
+    ("enc fc2 + fc1", 72000, (384, 1536), (1536, 384)), ("enc proj + qkv", 72000, (384, 384), (1152, 384)),
+    ("dec fc2 + fc1", 290000, (192, 768), (768, 192)), ("dec proj + qkv", 290000, (192, 192), (576, 192)),
+    ("vitb fc2 + fc1", 25088, (768, 3072), (3072, 768)), ("vitb proj + qkv", 25088, (768, 768), (2304, 768)),
+]
+
+
+def wgrad_pair_main(args, dev):
+    """One paired launch (mae_linear_wgrad_pair) against the two separate launches it replaces (MAE_WGRAD_PAIR=0)."""
+    g = torch.Generator(device=dev).manual_seed(1)
+    for name, M, (N0, K0), (N1, K1) in PAIRS:
+        if args.only and args.only not in name:
+            continue
+        t = {}
+        ops = []
+        for N, K in ((N0, K0), (N1, K1)):
+            ops.append(((torch.rand(M, N, device=dev, generator=g) * 2 - 1).to(torch.bfloat16), (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16),
+                        torch.empty(N, K, device=dev), torch.empty(N, device=dev)))
+        scratch = torch.empty(lib.mae_linear_wgrad_pair_scratch_bytes(M, N0, K0, N1, K1), dtype=torch.uint8, device=dev)
+        (y0, a0, w0, b0), (y1, a1, w1, b1) = ops
+
+        def run(mode):
+            os.environ["MAE_WGRAD_PAIR"] = mode
+            check(lib.mae_linear_wgrad_pair(_ptr(y0), _ptr(a0), N0, K0, _ptr(w0), _ptr(b0), _ptr(y1), _ptr(a1), N1, K1, _ptr(w1), _ptr(b1), M, BF16, _ptr(scratch), stream(dev)))
+        for mode in ("1", "0"):
+            run(mode); torch.cuda.synchronize()
+            ts = []
+            for _ in range(args.rounds):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); run(mode); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            t[mode] = sorted(ts)[len(ts) // 2]
+        fl = 2.0 * M * (N0 * K0 + N1 * K1)
+        print(f"{name:16s} M={M} | paired: {t['1']:7.1f} us {fl / t['1'] / 1e6:5.0f} TF/s | two launches: {t['0']:7.1f} us {fl / t['0'] / 1e6:5.0f} TF/s", flush=True)
+    os.environ.pop("MAE_WGRAD_PAIR", None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--variants", default="v1,v2")
     ap.add_argument("--only", default=None)
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient GEMM (+ slab reduce) instead")
+    ap.add_argument("--wgrad-pair", action="store_true", help="time the paired weight-gradient launch against the two launches it replaces")
     ap.add_argument("--wgrad-variants", default="v2", help="comma list of MAE_WGRAD values to A/B (v1 | v2 | v2r | v3 | v3r)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.wgrad_pair:
+        return wgrad_pair_main(args, dev)
     if args.wgrad:
         return wgrad_main(args, dev)
     variants = args.variants.split(",")
