@@ -63,6 +63,17 @@ __device__ __forceinline__ void st8(float* p, const f32x4& a, const f32x4& b) {
 __device__ __forceinline__ void st8(bf16* p, const f32x4& a, const f32x4& b) {
   stream_store(bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]}, reinterpret_cast<bf16x8*>(p));
 }
+__device__ __forceinline__ bf16x8 pk8(const f32x4& a, const f32x4& b) {
+  return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+}
+// the 16 bytes of the lane 8 places away inside its 16-lane row (DPP row_ror:8; lanes l and l ^ 8 swap)
+__device__ __forceinline__ bf16x8 row_swap8(const bf16x8& v) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+  u32x4_ x = __builtin_bit_cast(u32x4_, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[i], 0x128, 0xf, 0xf, true);
+  return __builtin_bit_cast(bf16x8, x);
+}
 __device__ __forceinline__ void glds16(const bf16* src, char* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
@@ -257,6 +268,85 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
             acc[mi][2 * j + 1][r] = __uint_as_float(sw[1]);
           }
       const float* sbias = reinterpret_cast<const float*>(smem + G_::BIAS_OFF + (ct & 1) * (BN * 4)) + wn * (NI * 16);
+#if !defined(MAE_DBG_NT_HALF_LINES) && !defined(MAE_DBG_NO_EPI) && !defined(MAE_DBG_EPI_LINEAR) && !defined(MAE_DBG_EPI_NOGELU) && \
+    !defined(MAE_DBG_EPI_NOSTORE) && !defined(MAE_DBG_EPI_ONESTORE)
+      if constexpr (sizeof(TO) == 2) {
+        // bf16 outputs, WHOLE-LINE stores.  A lane holds 8 consecutive columns (16 B) of one row and the 4 lanes of a row 64 B:
+        // written unit by unit, every store instruction covers 16 rows x half a line, and the other half of each line arrives
+        // with a later instruction (measured: whole-line stores are worth 13 us of 180 on fc1 + GELU, 28 us of 162 without the
+        // GELU arithmetic, r02_nt2_epilogue_ablation.txt).  Here two neighbouring 32-column groups whose 128 bytes form one
+        // aligned line are stored together: the lanes of rows 0-7 and of rows 8-15 swap one group's 16 bytes (DPP row_ror:8),
+        // so that one instruction writes rows 0-7 x 128 B and the next rows 8-15 x 128 B.  The wave's 96 (NI = 6) columns are
+        // a line and a half: the wave with the even column offset pairs groups (0, 1), the other one (1, 2); the group left
+        // over shares its line with the neighbouring wave and goes out as before.  NI = 4: one pair, nothing left over.
+        constexpr int NJ = NI / 2;
+        constexpr bool TWO = MODE == MAE_EPI_GELU || MODE == MAE_EPI_GELU_GRAD;
+        const bool lo8 = fr < 8;
+        const int colw = n0 + wn * (NI * 16) + 4 * gb;      // this lane's column inside group 0
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int64_t mrow = m0 + wm * WROWS + mi * 16;   // first row of the 16-row group
+          const int64_t m = mrow + fr;
+          bf16x8 pa[NJ], pb[TWO ? NJ : 1];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int nl = 32 * j + 4 * gb;
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (HAS_BIAS) { b0 = load4(sbias + nl); b1 = load4(sbias + nl + 4); }
+            f32x4 v0 = acc[mi][2 * j] + b0, v1 = acc[mi][2 * j + 1] + b1;
+            if (MODE == MAE_EPI_GELU || MODE == MAE_EPI_GELU_GRAD || MODE == MAE_EPI_GELU_ACT) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v0[r] = to_f(from_f<TO>(v0[r]));
+                v1[r] = to_f(from_f<TO>(v1[r]));
+              }
+              f32x4 a0, a1, g0, g1;
+              gelu_fast_pair(v0, a0, g0);
+              gelu_fast_pair(v1, a1, g1);
+              if (MODE == MAE_EPI_GELU) { pa[j] = pk8(v0, v1); pb[TWO ? j : 0] = pk8(a0, a1); }
+              else if (MODE == MAE_EPI_GELU_GRAD) { pa[j] = pk8(g0, g1); pb[TWO ? j : 0] = pk8(a0, a1); }
+              else pa[j] = pk8(a0, a1);
+            } else if (MODE == MAE_EPI_DGELU || MODE == MAE_EPI_MUL) {
+              f32x4 q0, q1;
+              if (PREF) unpack8(qa[PREF ? j : 0][PREF ? mi : 0], q0, q1);
+              else {
+                const int64_t mc = m < M ? m : M - 1;
+                ld8(reinterpret_cast<const TO*>(aux) + mc * N + colw + 32 * j, q0, q1);
+              }
+              if (MODE == MAE_EPI_DGELU) { f32x4 a_, g_; gelu_fast_pair(q0, a_, g_); v0 *= g_; gelu_fast_pair(q1, a_, g_); v1 *= g_; }
+              else { v0 *= q0; v1 *= q1; }
+              pa[j] = pk8(v0, v1);
+            } else {
+              pa[j] = pk8(v0, v1);
+            }
+            acc[mi][2 * j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[mi][2 * j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          // ja = first group of the aligned pair (wave-uniform; NI = 6: 0 for the wave at column offset 0, 1 for the other)
+          auto store_rows = [&](TO* __restrict__ dst, const bf16x8* pk, int ja) {
+            const bf16x8 A = pk[ja], Bv = pk[ja + 1];
+            const bf16x8 R = row_swap8(lo8 ? Bv : A);                      // rows 0-7 hand over group ja + 1, rows 8-15 group ja
+            const int col = colw + 32 * (lo8 ? ja : ja + 1);
+            const int64_t r1 = mrow + (fr & 7), r2 = r1 + 8;
+            if (r1 < M) stream_store(lo8 ? A : R, reinterpret_cast<bf16x8*>(dst + r1 * N + col));   // rows 0-7: 128 B each
+            if (r2 < M) stream_store(lo8 ? R : Bv, reinterpret_cast<bf16x8*>(dst + r2 * N + col));  // rows 8-15
+          };
+          auto store_single = [&](TO* __restrict__ dst, const bf16x8& v, int j) {
+            if (m < M) stream_store(v, reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j));
+          };
+          if (NJ == 2) {
+            store_rows(out, pa, 0);
+            if (TWO) store_rows(out2, pb, 0);
+          } else if (wn == 0) {
+            store_rows(out, pa, 0); store_single(out, pa[NJ - 1], NJ - 1);
+            if (TWO) { store_rows(out2, pb, 0); store_single(out2, pb[TWO ? NJ - 1 : 0], NJ - 1); }
+          } else {
+            store_single(out, pa[0], 0); store_rows(out, pa, NJ - 2);
+            if (TWO) { store_single(out2, pb[0], 0); store_rows(out2, pb, TWO ? NJ - 2 : 0); }
+          }
+        }
+      } else
+#endif
 #pragma unroll
       for (int j = 0; j < NI / 2; ++j) {
         const int nl = 32 * j + 4 * gb;  // column inside the wave's NI*16
