@@ -105,6 +105,34 @@ def test_two_fused_steps_match_oracle(dev, precision, tol):
         assert torch.equal(sd[n].cpu(), params[n])
 
 
+def test_twelve_fused_steps_track_the_oracle(dev):
+    """A longer trajectory than the two-step check: twelve whole steps (fresh images and masks each step, warm-up learning
+    rate, clip active at first) in the fp32 engine against oracle.train_step; the loss of every step within 2e-4 relative, the
+    parameters after the last step within 2e-4 -- rounding differences must not compound."""
+    cfg, B = MICRO, 6
+    tcfg = dict(mask_ratio_start=0.75, mask_ratio_end=0.75, mask_ramp_epochs=5, total_epochs=800, warmup_epochs=20,
+                batch_size=2000, base_learning_rate=1.5e-4, weight_decay=0.05)
+    g, e, d = cfg_dicts(cfg, "fp32")
+    module = MAEPretrainModule(dict(general=g, encoder=e, decoder=d), tcfg)
+    params = O.init_params(cfg, 73); O.randomize_params(params)
+    module.model.load_state_dict(params)
+    module = module.to(dev)
+    module.on_train_epoch_start()
+    lr = O.effective_lr(1.5e-4, 2000) * O.lr_lambda(0, 20, 800)
+    state, losses = {}, []
+    for step in range(1, 13):
+        images = O.synthetic_images(B, cfg, seed=300 + step)
+        noise = O.make_noise(B, cfg.sequence_length, torch.Generator().manual_seed(500 + step))
+        loss_ref, _aux = O.train_step(params, cfg, state, images, noise, lr, step)
+        loss = module.fused_training_step(images.to(dev), noise.to(dev))
+        losses.append((loss.item(), loss_ref.item()))
+    for got, ref in losses:
+        assert abs(got - ref) <= 2e-4 * abs(ref), losses
+    sd = module.model.state_dict()
+    for n in O.trainable_names(cfg):
+        assert rel_err(sd[n], params[n]) < 2e-4, n
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_autograd_path_equals_fused_path(dev, precision):
     cfg, B = MICRO, 3
