@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
             acc[mi][2 * j + 1][r] = __uint_as_float(sw[1]);
           }
       const float* sbias = reinterpret_cast<const float*>(smem + G_::BIAS_OFF + (ct & 1) * (BN * 4)) + wn * (NI * 16);
-#if !defined(MAE_DBG_NT_HALF_LINES) && !defined(MAE_DBG_NO_EPI) && !defined(MAE_DBG_EPI_LINEAR) && !defined(MAE_DBG_EPI_NOGELU) && \
+#if !defined(MAE_DBG_NT_HALF_LINES) && !defined(MAE_DBG_NO_EPI) && !defined(MAE_DBG_EPI_NOGELU) && \
     !defined(MAE_DBG_EPI_NOSTORE) && !defined(MAE_DBG_EPI_ONESTORE)
       if constexpr (sizeof(TO) == 2) {
         // bf16 outputs, WHOLE-LINE stores.  A lane holds 8 consecutive columns (16 B) of one row and the 4 lanes of a row 64 B:
@@ -360,12 +360,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt2_kernel(const bf16* __restrict
 #else
           if (m < M) {
 #endif
-#ifdef MAE_DBG_EPI_LINEAR
-            // timing probe only (wrong layout): every store instruction of a wave writes 1 KiB of whole 128-byte lines
-            const int64_t o = ((int64_t)t * (BM2 * BN)) + (((wave * MI + mi) * (NI / 2) + j) * 64 + lane) * 8;
-#else
             const int64_t o = m * N + n0 + wn * (NI * 16) + nl;
-#endif
             f32x4 v0 = acc[mi][2 * j] + b0, v1 = acc[mi][2 * j + 1] + b1;
             if (MODE == MAE_EPI_GELU) {
               f32x4 a0, a1;
