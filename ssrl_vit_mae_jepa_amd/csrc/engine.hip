@@ -290,13 +290,19 @@ struct Ctx {
   template <class T = void> T* buf(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
 };
 
-static double gemm_bytes(int64_t M, int N, int K, int64_t as, int64_t os) { return (double)(M * K * as + (int64_t)N * K * as + M * N * os); }
+// algorithmic HBM bytes of one Linear launch: both operands, every output (the GELU epilogues write two) and the (M,N) side input
+// of the RESID (fp32 residual) / MUL / DGELU (output-typed) epilogues
+static double gemm_bytes(int64_t M, int N, int K, int64_t as, int64_t os, int mode = MAE_EPI_NONE) {
+  const int64_t outs = (mode == MAE_EPI_GELU || mode == MAE_EPI_GELU_GRAD) ? 2 : 1;
+  const int64_t side = mode == MAE_EPI_RESID ? 4 : (mode == MAE_EPI_MUL || mode == MAE_EPI_DGELU) ? os : 0;
+  return (double)(M * K * as + (int64_t)N * K * as + M * N * (outs * os + side));
+}
 
 static int linear(const Ctx& c, const void* A, int wi, int bi, int64_t M, int N, int K, int mode, int out_dt, void* out, void* out2,
                   const void* aux) {
   mae_engine* e = c.e; hipStream_t s = c.s;
   Epi ep; ep.mode = mode; ep.bias = bi >= 0 ? c.P(bi) : nullptr; ep.aux = aux; ep.out = out; ep.out2 = out2; ep.out_dt = out_dt;
-  RUN(TK_LINEAR, 2.0 * M * N * K, gemm_bytes(M, N, K, c.as, (int64_t)dtype_size(out_dt)), launch_linear_fwd(A, c.W(wi), M, N, K, c.act, ep, s));
+  RUN(TK_LINEAR, 2.0 * M * N * K, gemm_bytes(M, N, K, c.as, (int64_t)dtype_size(out_dt), mode), launch_linear_fwd(A, c.W(wi), M, N, K, c.act, ep, s));
   return 0;
 }
 
@@ -305,9 +311,9 @@ static int dgrad(const Ctx& c, const void* dY, int wi, int64_t M, int N, int K, 
   mae_engine* e = c.e; hipStream_t s = c.s;
   Epi ep; ep.mode = mode; ep.aux = aux; ep.out = out; ep.out_dt = c.act;
   if (c.act == MAE_BF16) {
-    RUN(TK_LINEAR, 2.0 * M * N * K, gemm_bytes(M, K, N, 2, 2), launch_linear_fwd(dY, c.WT(wi), M, K, N, MAE_BF16, ep, s));
+    RUN(TK_LINEAR, 2.0 * M * N * K, gemm_bytes(M, K, N, 2, 2, mode), launch_linear_fwd(dY, c.WT(wi), M, K, N, MAE_BF16, ep, s));
   } else {
-    RUN(TK_LINEAR, 2.0 * M * N * K, gemm_bytes(M, K, N, 4, 4), launch_linear_dgrad(dY, c.W(wi), M, N, K, MAE_F32, ep, s));
+    RUN(TK_LINEAR, 2.0 * M * N * K, gemm_bytes(M, K, N, 4, 4, mode), launch_linear_dgrad(dY, c.W(wi), M, N, K, MAE_F32, ep, s));
   }
   return 0;
 }

@@ -14,6 +14,9 @@ int mfma_linear_fwd(const bf16* A, const bf16* W, int64_t M, int N, int K, const
 // persistent LDS-DMA ring variant (k_gemm_mfma2.hip): NONE / GELU epilogues, N % 128 == 0, K % 64 == 0, K >= 192
 int mfma_linear_fwd_v2(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& epi, hipStream_t s);
 
+// round-3 K-loop on the same tiles (k_gemm_nt3.hip): NONE / GELU_GRAD / GELU_ACT / MUL epilogues, same shapes as v2
+int mfma_linear_fwd_v3(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& epi, hipStream_t s);
+
 // dW[N,K] = dY[M,N]^T * A[M,K] (fp32, written)
 int64_t mfma_wgrad_scratch_bytes(int64_t M, int N, int K);
 // also db[N] = column sums of dY when db != null

@@ -137,7 +137,11 @@ int launch_linear_fwd(const void* A, const void* W, int64_t M, int N, int K, int
   MAE_REQUIRE(A && W && M > 0 && N > 0 && K > 0, "linear_fwd: bad arguments");
   MAE_TRY(check_epi(e, dt, "linear_fwd"));
   if (dt == MAE_BF16) {
-    const char* var = getenv("MAE_GEMM_NT");  // "v1" pins the per-tile kernel (A/B runs in tools/gemm_bench.py)
+    const char* var = getenv("MAE_GEMM_NT");  // "v1" pins the per-tile kernel, "v2" round 2's ring kernel (A/B runs in tools/gemm_bench.py)
+    if (var && var[0] == 'v' && var[1] == '3') {
+      const int r3 = mfma_linear_fwd_v3((const bf16*)A, (const bf16*)W, M, N, K, e, s);
+      if (r3 != MFMA_UNSUPPORTED) return r3;
+    }
     if (!(var && var[0] == 'v' && var[1] == '1')) {
       const int r2 = mfma_linear_fwd_v2((const bf16*)A, (const bf16*)W, M, N, K, e, s);
       if (r2 != MFMA_UNSUPPORTED) return r2;

@@ -7,7 +7,7 @@ set -e
 ROOT=$PWD
 TAG=${1:-}
 if [ -n "$TAG" ]; then shift; OUT=$ROOT/gpurun_out/evidence_$TAG; else OUT=$ROOT/gpurun_out/evidence; fi
-ARGS="$*"
+ARGS=$(echo "$*" | sed "s#configs/#$ROOT/configs/#g")   # rocprofv3 runs from /tmp: absolute config path
 rm -rf $OUT; mkdir -p $OUT
 python bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp

@@ -53,7 +53,7 @@ def wgrad_main(args, dev):
     variants = args.wgrad_variants.split(",")
     g = torch.Generator(device=dev).manual_seed(1)
     for name, M, N, K in WGRAD_SHAPES:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(',')):
             continue
         dY = (torch.rand(M, N, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
         A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
@@ -93,7 +93,7 @@ def wgrad_pair_main(args, dev):
     """One paired launch (mae_linear_wgrad_pair) against the two separate launches it replaces (MAE_WGRAD_PAIR=0)."""
     g = torch.Generator(device=dev).manual_seed(1)
     for name, M, (N0, K0), (N1, K1) in PAIRS:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(',')):
             continue
         t = {}
         ops = []
@@ -122,7 +122,7 @@ def wgrad_pair_main(args, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--variants", default="v1,v2")
+    ap.add_argument("--variants", default="v2,v3")
     ap.add_argument("--only", default=None)
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient GEMM (+ slab reduce) instead")
     ap.add_argument("--wgrad-pair", action="store_true", help="time the paired weight-gradient launch against the two launches it replaces")
@@ -136,7 +136,7 @@ def main():
     variants = args.variants.split(",")
     g = torch.Generator(device=dev).manual_seed(1)
     for name, M, N, K, epi, odt in SHAPES:
-        if args.only and args.only not in name:
+        if args.only and not any(o in name for o in args.only.split(',')):
             continue
         A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
         W = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
