@@ -1,24 +1,32 @@
-// Persistent bf16 MFMA NT GEMM for gfx950, v3 (round 3): the tiles, LDS image and epilogues of gemm_nt2_kernel with a new K-loop.
+// Persistent bf16 MFMA NT GEMM for gfx950, v3 (round 3): the tiles, fragment layout and epilogues of gemm_nt2_kernel with a new K-loop.
 //
 //   out[M,N] = A[M,K] * W[N,K]^T (+bias) with the NONE / GELU_GRAD / GELU_ACT / MUL epilogues the engine's bf16 path uses.
 //
-// What round 2's kernel lost, read off its ISA and off tools/micro/rates_probe.hip (profiles/r03_rates_probe.txt):
+// What round 2's kernel lost, read off its ISA and off tools/micro/{rates,dma_mfma}_probe.hip (profiles/r03_nt3_kloop.txt):
 //   * hipcc reused ONE fragment register set for both 32-deep halves of a K-step, so every wave ran
-//     read - wait - 24 MFMAs - read - wait - 24 MFMAs, all eight waves in the same phase: the matrix pipe idled while the LDS
-//     served the 80 reads of a burst.  The same wave tile with two fragment sets and the reads of the next half issued
-//     between the MFMAs of the current one keeps the pipe at 16.5 cycles per MFMA (2.0 PFLOP/s in the probe).
-//   * the DMA issue (7 per wave and K-step, tile-switch logic with divisions, clamps and 64-bit pointers inlined per piece)
-//     sat between the first reads and the first MFMA.  Here a piece is `s_mov m0` + ONE `buffer_load_dwordx4 ... lds` whose
-//     per-lane offset never changes (row-in-group x row pitch + swizzled chunk) and whose tile / group / K-step position is
-//     a scalar offset; rows past M need no clamp (the buffer descriptor's range check returns zeros); pieces go out one at a
-//     time between pairs of MFMAs.
-//   * the activation panel of a tile is first touched in HBM by the DMAs that need it one K-step later (a 2-stage ring cannot
-//     look further ahead, 3 x 56 KiB do not fit): every K-step of every workgroup sharing the panel waited for HBM.  Here each
-//     wave also issues one 4-byte-per-lane DMA per K-step that touches one line of 32 rows of the NEXT tile's panel: the panel
-//     is in L2 a whole tile before its first use (an L2 prefetch; the bytes land in a 256-byte scratch strip).
-//   * MFMAs run one half-step BEHIND the reads (the last half of a tile is multiplied at the top of the next tile's first
-//     step, before that tile's epilogue), so the wait + barrier at the top of a step is covered by MFMAs already queued.
-// Same accumulation order per output element as v2 (K ascending in 32-deep chunks): bit-identical results.
+//     read - wait - 24 MFMAs - read - wait - 24 MFMAs, all eight waves in the same phase.  Here: two fragment sets, the reads of
+//     the next half issued between the MFMAs of the current one, MFMAs one half-step BEHIND the reads (the last half of a tile
+//     is multiplied at the top of the next tile's first step, before that tile's epilogue).  Rebuilt in the probe, this K-step
+//     with its 7 DMA pieces per wave, counted wait and barrier runs at 760 ns = 2.1 PFLOP/s when every piece hits L2.
+//   * it does not when the activation rows are first touched in HBM one step before they are needed: 1300 ns.  A tile's row
+//     panel is new to the chip, the tiles_n workgroups that share it (same XCD) ask for the same slice at the same time, and a
+//     two-stage ring has one step of lookahead: every step of every sharer waits for HBM.  Two changes, both measured in the
+//     probe (1300 -> 960 -> 880 ns):
+//       - SPLIT RINGS: weight rows always hit L2 (one step of lookahead is enough: 2 stages), so the LDS the third stage of a
+//         uniform ring would need goes to the activation rows alone: 3 x 32 KiB (256-row tiles) or 4 x 24 KiB (192-row tiles),
+//         two / three steps of lookahead.  A wave issues its weight pieces first and its activation pieces after them, so
+//         that the in-order vmcnt can wait for the young weight pieces while the younger activation pieces stay in flight.
+//       - ROTATED K ORDER: the sharers of a panel walk its K-steps from different starting points ((k + rot(tn)) mod nk), so
+//         that at any time they ask for different slices: a slice's first request pays HBM, the other sharers find it in L2.
+//         (The per-element summation order over K therefore depends on the tile column; deterministic, not bit-equal to v2.
+//         -DMAE_NT3_NOROT keeps K ascending: that build is bit-identical to v2, tools/gemm_bench.py.)
+//   * a DMA piece is `s_mov m0` + ONE `buffer_load_dwordx4 ... lds` whose per-lane offset never changes (row-in-group x row pitch
+//     + swizzled chunk) and whose tile / group / K-step position is a scalar offset; rows past M need no clamp (the buffer
+//     descriptor's range check returns zeros); pieces go out one at a time between pairs of MFMAs, all of them in the first
+//     half of a step (before the epilogue's stores, which the counted waits then allow to stay in flight).
+//   Tried and dropped (same file): an L2 prefetch of the NEXT tile's panel by 4-byte-per-lane DMAs (a whole tile ahead it thrashes
+//   L2 on the narrow-N shapes and costs as many tag lookups as half the pieces: 5-10 % slower), pieces spread over both halves of
+//   a step or issued by the two waves of a SIMD in different halves (2-5 % slower).
 #include "gemm_mfma.h"
 #include <cstdlib>
 
@@ -28,33 +36,19 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int BK3 = 64;
-// experiment knobs (alternate builds only; see profiles/r03_nt3_kloop_ab.txt):
-//   MAE_NT3_SCHED  0: every DMA piece of a step goes out in phase 1; 1: even pieces in phase 1, odd pieces in phase 2;
-//                  2: waves 0-3 issue in phase 1, waves 4-7 (their partners on the SIMDs) in phase 2.  A step that runs an
-//                  epilogue always issues everything in phase 1, before the stores (the counted waits rely on that order).
-//   MAE_NT3_NOPF   no L2 prefetch of the next tile's activation panel
-#ifndef MAE_NT3_SCHED
-#define MAE_NT3_SCHED 0
-#endif
-#ifdef MAE_NT3_NOPF
-constexpr int NT3_PF = 0;
-#else
-constexpr int NT3_PF = 1;
-#endif
-
 template <int NI, int MI>
 struct Geo3 {
   static constexpr int BN = 32 * NI, BM = 64 * MI;
-  static constexpr int STAGE = (BM + BN) * BK3 * 2;                   // A rows first, then W rows, 128 B per row
-  static constexpr int TAIL = 2 * BN * 4 + 256;                       // bias strips of two tiles + the L2-prefetch scratch strip
-  static constexpr int NSTAGE = (3 * STAGE + TAIL <= 160 * 1024) ? 3 : 2;
-  static constexpr int AHEAD = NSTAGE - 1;
-  static constexpr int BIAS_OFF = NSTAGE * STAGE;
-  static constexpr int PF_OFF = BIAS_OFF + 2 * BN * 4;
-  static constexpr int LDS = PF_OFF + 256;
-  static constexpr int GPW = (BM + BN) / 64;                          // 1 KiB DMA pieces (8 rows) per wave and stage
+  static constexpr int ASTG = BM * BK3 * 2, WSTG = BN * BK3 * 2;      // one K-step of activation rows / of weight rows, 128 B per row
+  static constexpr int TAIL = 2 * BN * 4;                             // bias strips of two tiles
+  static constexpr int SW = 2;                                        // weight ring: L2 hits, one step ahead
+  static constexpr int SA = (160 * 1024 - TAIL - SW * WSTG) / ASTG >= 4 ? 4 : 3;   // activation ring: 2 or 3 steps ahead
+  static constexpr int A_OFF = 0, W_OFF = SA * ASTG, BIAS_OFF = W_OFF + SW * WSTG;
+  static constexpr int LDS = BIAS_OFF + TAIL;
+  static constexpr int NA = BM / 64, NW = BN / 64;                    // 1 KiB DMA pieces (8 rows) per wave and step: activation, weight
+  static constexpr int GPW = NA + NW;
   static constexpr int NBIAS = BN / 64;
-  static_assert((BM + BN) % 64 == 0, "DMA pieces must divide evenly over the 8 waves");
+  static_assert(LDS <= 160 * 1024 && BM % 64 == 0 && BN % 64 == 0, "LDS budget / even deal of the pieces over the 8 waves");
 };
 
 __device__ __forceinline__ void unpack8(const bf16x8& v, f32x4& a, f32x4& b) {
@@ -134,13 +128,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
                                                           TO* __restrict__ out2, int tiles_m, int tiles_n) {
   using G_ = Geo3<NI, MI>;
   using SP = Spread<MI, NI, G_::GPW>;
-  constexpr int BM = G_::BM, BN = G_::BN, STAGE = G_::STAGE, NSTAGE = G_::NSTAGE, AHEAD = G_::AHEAD, GPW = G_::GPW;
-  constexpr int NB = HAS_BIAS ? G_::NBIAS : 0;
+  constexpr int BM = G_::BM, BN = G_::BN, ASTG = G_::ASTG, WSTG = G_::WSTG, SA = G_::SA, SW = G_::SW, NA = G_::NA, NW = G_::NW, GPW = G_::GPW;
   constexpr int NJ = NI / 2, NR = MI + NI;
   constexpr bool TWO = MODE == MAE_EPI_GELU_GRAD;
   constexpr int STORE8 = sizeof(TO) == 2 ? 1 : 2;          // store instructions per 8 outputs
   constexpr int E = MI * NJ * STORE8 * (TWO ? 2 : 1);      // epilogue stores per wave (full tile)
-  constexpr int GRP = GPW + NT3_PF;                        // vector-memory operations per issued stage: the pieces + the L2 prefetch
+  static_assert(SW == 2, "the waits below assume weight pieces one step ahead");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,47 +148,64 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
   const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
   const uint32_t rowbytes = (uint32_t)K * 2u;
 
-  // ---- producer side (all scalar but three per-lane offsets that never change)
+  // ---- producer side: two DMA streams (weight rows one step ahead, activation rows SA - 1 steps ahead), all scalar but two
+  // per-lane offsets that never change.  Every wave owns NA activation pieces and NW weight pieces of a step.
   const i32x4 rsA = make_rsrc(A, (uint32_t)((uint64_t)M * rowbytes));
   const i32x4 rsW = make_rsrc(W, (uint32_t)N * rowbytes);
   const i32x4 rsB = make_rsrc(bias, HAS_BIAS ? (uint32_t)N * 4u : 0u);
   const uint32_t r8 = (uint32_t)lane >> 3;
   const uint32_t voff = r8 * rowbytes + ((((uint32_t)lane & 7u) ^ r8) << 4);   // row r8 of an 8-row piece, swizzled source chunk for LDS slot lane & 7
-  const uint32_t voff_pf = (uint32_t)(wave * (BM / 8) + (lane % (BM / 8))) * rowbytes;  // one line of each of BM / 8 rows of the next tile's panel
   const uint32_t voff_b = (uint32_t)lane * 4u;
   const int dq = G / tiles_n, dr = G % tiles_n;            // tile id + G in (row, column) form, without a division per tile
-  int i_tm = vb / tiles_n, i_tn = vb % tiles_n;            // tile the DMA stream is in
-  int n_tm = i_tm + dq, n_tn = i_tn + dr;                  // the tile after it
-  if (n_tn >= tiles_n) { n_tn -= tiles_n; ++n_tm; }
-  int i_tile = 0, i_k = 0, i_stage = 0;
-  uint32_t sA = (uint32_t)i_tm * BM * rowbytes, sW = (uint32_t)i_tn * BN * rowbytes;
-  uint32_t sPF = ntile > 1 ? (uint32_t)n_tm * BM * rowbytes : 0xffffff00u;     // no next tile: out of range, fetches nothing
-  auto issue_piece = [&](int q) {
-    const int g = wave * GPW + q;
-    const bool isA = g < BM / 8;
-    const uint32_t soff = (isA ? sA + (uint32_t)(g * 8) * rowbytes : sW + (uint32_t)((g - BM / 8) * 8) * rowbytes) + (uint32_t)i_k * 128u;
+  // K order of a tile, rotated by its column so that the tiles_n workgroups sharing a row panel ask for different slices
+#ifdef MAE_NT3_NOROT
+  const int rot_mul = 0;
+#else
+  const int rot_mul = nk >= tiles_n ? nk / tiles_n : 1;
+#endif
+  struct Stream { int tm, tn, k, kk, tile, stage; };       // tile (row, column), step inside it, rotated K index, tile ordinal, ring stage
+  auto stream_init = [&](Stream& st) { st.tm = vb / tiles_n; st.tn = vb % tiles_n; st.k = 0; st.kk = (st.tn * rot_mul) % nk; st.tile = 0; st.stage = 0; };
+  auto stream_next = [&](Stream& st, int nstage) {
+    st.stage = st.stage == nstage - 1 ? 0 : st.stage + 1;
+    st.kk = st.kk == nk - 1 ? 0 : st.kk + 1;
+    if (++st.k == nk) {
+      st.k = 0; ++st.tile;
+      st.tm += dq; st.tn += dr;
+      if (st.tn >= tiles_n) { st.tn -= tiles_n; ++st.tm; }
+      st.kk = (st.tn * rot_mul) % nk;
+    }
+  };
+  Stream sa, sw;
+  stream_init(sa); stream_init(sw);
+  auto issue_a = [&](int q) {   // activation piece q of this wave: rows 8 (wave NA + q) .. + 7 of the panel
+    const int g = wave * NA + q;
 #ifndef MAE_DBG_NO_DMA
-    dma16(isA ? rsA : rsW, lds0 + (uint32_t)(i_stage * STAGE + g * 1024), voff, soff);
+#if defined(MAE_DBG_NT3_ONLY_W)
+#elif defined(MAE_DBG_NT3_DMA_FIXED)   // timing probes, wrong values: every piece reads the same KiB (L1-resident) ...
+    dma16(rsA, lds0 + (uint32_t)(G_::A_OFF + sa.stage * ASTG + g * 1024), (uint32_t)lane * 16u, (uint32_t)wave * 1024u);
+#elif defined(MAE_DBG_NT3_A_RESIDENT)   // ... every tile reads the first row panel (L2-resident after its first use)
+    dma16(rsA, lds0 + (uint32_t)(G_::A_OFF + sa.stage * ASTG + g * 1024), voff, ((uint32_t)(g * 8)) * rowbytes + (uint32_t)sa.kk * 128u);
+#else
+    dma16(rsA, lds0 + (uint32_t)(G_::A_OFF + sa.stage * ASTG + g * 1024), voff, ((uint32_t)sa.tm * BM + (uint32_t)(g * 8)) * rowbytes + (uint32_t)sa.kk * 128u);
+#endif
 #endif
   };
-  auto issue_tail = [&]() {   // the tile's bias strip rides with its first K-step; the L2 prefetch; advance the stream
-#ifndef MAE_DBG_NO_DMA
-    if (HAS_BIAS && i_k == 0) {
-#pragma unroll
-      for (int i = 0; i < G_::NBIAS; ++i) dma4(rsB, lds0 + (uint32_t)(G_::BIAS_OFF + (i_tile & 1) * (BN * 4) + 256 * i), voff_b, (uint32_t)(i_tn * BN * 4 + 256 * i));
-    }
-    if (NT3_PF) dma4(rsA, lds0 + (uint32_t)G_::PF_OFF, voff_pf, sPF + (uint32_t)i_k * 128u);
+  auto issue_w = [&](int q) {
+    const int g = wave * NW + q;
+#if defined(MAE_DBG_NO_DMA) || defined(MAE_DBG_NT3_ONLY_A)
+#elif defined(MAE_DBG_NT3_DMA_FIXED)
+    dma16(rsW, lds0 + (uint32_t)(G_::W_OFF + sw.stage * WSTG + g * 1024), (uint32_t)lane * 16u, (uint32_t)wave * 1024u);
+#else
+    dma16(rsW, lds0 + (uint32_t)(G_::W_OFF + sw.stage * WSTG + g * 1024), voff, ((uint32_t)sw.tn * BN + (uint32_t)(g * 8)) * rowbytes + (uint32_t)sw.kk * 128u);
 #endif
-    i_stage = i_stage == NSTAGE - 1 ? 0 : i_stage + 1;
-    if (++i_k == nk) {
-      i_k = 0;
-      ++i_tile;
-      i_tm = n_tm; i_tn = n_tn;
-      n_tm += dq; n_tn += dr;
-      if (n_tn >= tiles_n) { n_tn -= tiles_n; ++n_tm; }
-      sA = (uint32_t)i_tm * BM * rowbytes; sW = (uint32_t)i_tn * BN * rowbytes;
-      sPF = i_tile + 1 < ntile ? (uint32_t)n_tm * BM * rowbytes : 0xffffff00u;
+  };
+  auto issue_bias = [&]() {     // the tile's bias strip rides with the weight pieces of its first step (every wave writes the same bytes)
+#ifndef MAE_DBG_NO_DMA
+    if (HAS_BIAS && sw.k == 0) {
+#pragma unroll
+      for (int i = 0; i < G_::NBIAS; ++i) dma4(rsB, lds0 + (uint32_t)(G_::BIAS_OFF + (sw.tile & 1) * (BN * 4) + 256 * i), voff_b, (uint32_t)(sw.tn * BN * 4 + 256 * i));
     }
+#endif
   };
 
   f32x4 acc[MI][NI];
@@ -213,23 +223,27 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
     for (int j = 0; j < NI; ++j) bf1[j] = zz;
   }
 
+  // prologue: activation steps 0 .. SA - 2, then weight step 0 (the youngest: the first wait drains everything)
 #pragma unroll
-  for (int q = 0; q < GPW; ++q) issue_piece(q);
-  issue_tail();
-  if (AHEAD > 1 && nsteps > 1) {
+  for (int a = 0; a < SA - 1; ++a)
+    if (a < nsteps) {
 #pragma unroll
-    for (int q = 0; q < GPW; ++q) issue_piece(q);
-    issue_tail();
-  }
+      for (int q = 0; q < NA; ++q) issue_a(q);
+      stream_next(sa, SA);
+    }
+#pragma unroll
+  for (int q = 0; q < NW; ++q) issue_w(q);
+  issue_bias();
+  stream_next(sw, SW);
 
   // ---- consumer side
   const int sw0 = ((0 + fq) ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
   const int gb = (fq & 1) ? 3 + fq : fq;
-  const int a_lane = (wm * WROWS + fr) * 128, b_lane = BM * 128 + (wn * (NI * 16) + fr) * 128;
+  const int a_lane = G_::A_OFF + (wm * WROWS + fr) * 128, b_lane = G_::W_OFF + (wn * (NI * 16) + fr) * 128;
   int c_tm = vb / tiles_n, c_tn = vb % tiles_n;   // tile being multiplied
   int64_t p_m0 = 0;                               // tile whose epilogue is pending
   int p_n0 = 0, p_strip = 0;
-  int ct = 0, ck = 0, cs = 0;
+  int ct = 0, ck = 0, csa = 0, csw = 0;
   bool prev_full = false;
 
   auto epilogue = [&](int64_t m0, int n0, int strip) {
@@ -333,10 +347,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
     prev_full = m0 + BM <= M;
   };
 
-#define NT3_READ(AF, BF, SW)                                                                                       \
+
+#define NT3_READ(AF, BF, SWZ)                                                                                      \
   {                                                                                                                \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) AF[mi] = *reinterpret_cast<const bf16x8*>(stg + a_lane + mi * 2048 + (SW)); \
-    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) BF[ni] = *reinterpret_cast<const bf16x8*>(stg + b_lane + ni * 2048 + (SW)); \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) AF[mi] = *reinterpret_cast<const bf16x8*>(stg_a + a_lane + mi * 2048 + (SWZ)); \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) BF[ni] = *reinterpret_cast<const bf16x8*>(stg_w + b_lane + ni * 2048 + (SWZ)); \
   }
 #define NT3_IL(n)                                              \
   _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {        \
@@ -344,78 +359,94 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         \
   }
 
+#ifdef MAE_DBG_NT3_TRACE   // cycle breakdown of a step (alternate build; prints from three workgroups, perturbs the timing a little)
+  unsigned long long tr_top = 0, tr_p1 = 0, tr_epi = 0, tr_p2 = 0;
+  const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+#define NT3_TS(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define NT3_TS(var)
+#endif
   for (int step = 0; step < nsteps; ++step) {
-    // ---- wait for this step's stage.  Outstanding afterwards may be: the next stage (AHEAD == 2; + the bias pieces when it opens
-    // a tile) and the stores of an epilogue that ran after this stage had been issued (one or two steps ago; only counted when
-    // that tile was full, so that every store was issued)
+#ifdef MAE_DBG_NT3_TRACE
+    unsigned long long ta, tb, tc, td, te;
+#endif
+    NT3_TS(ta)
+    // ---- wait for this step's weight pieces (issued in the previous iteration; everything older, the step's activation pieces
+    // included, has retired by then).  Younger, and allowed to stay in flight: the activation pieces issued after them in that
+    // iteration, and the stores of an epilogue that ran there (counted only when that tile was full: every store was issued).
     {
-      const bool last = step + 1 >= nsteps;
-      const bool epi1 = ck == 1 && ct > 0 && prev_full;                      // the epilogue ran in the previous iteration
-      const bool epi2 = AHEAD == 2 && ck == 2 && ct > 0 && prev_full;        // ... two iterations ago
-      if (AHEAD == 2) {
-        const bool opens = ck == nk - 1, ep = epi1 || epi2;   // the stage after this one opens a tile (it carried the bias pieces)
-        if (last) wait_vm3<0>();
-        else if (opens && ep) wait_vm3<GRP + NB + E>();
-        else if (opens) wait_vm3<GRP + NB>();
-        else if (ep) wait_vm3<GRP + E>();
-        else wait_vm3<GRP>();
-      } else {
-        if (epi1) wait_vm3<E>();
-        else wait_vm3<0>();
-      }
+      const bool a_prev = step > 0 && step + SA - 2 < nsteps;               // the previous iteration issued activation pieces
+      const bool epi1 = ck == 1 && ct > 0 && prev_full;                      // ... and ran an epilogue
+#ifdef MAE_DBG_NT3_B1   // bisection builds (timing only)
+      wait_vm3<0>();
+#else
+      if (a_prev && epi1) wait_vm3<NA + E>();
+      else if (a_prev) wait_vm3<NA>();
+      else if (epi1) wait_vm3<E>();
+      else wait_vm3<0>();
+#endif
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the stage refilled below have landed in its registers
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the stages refilled below have landed in its registers
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
-    const char* stg = smem + cs * STAGE;
-    const bool do_issue = step + AHEAD < nsteps;
+    const char* stg_a = smem + csa * ASTG;
+    const char* stg_w = smem + csw * WSTG;
+#ifdef MAE_DBG_NT3_B2
+    const bool do_w = true, do_a = true;
+#else
+    const bool do_w = step + 1 < nsteps, do_a = step + SA - 1 < nsteps;
+#endif
+    NT3_TS(tb)
 
-    // ---- phase 1: reads of half 0 beside the MFMAs of the previous step's half 1, then the DMA pieces between the other MFMAs
+    // ---- phase 1: reads of half 0 beside the MFMAs of the previous step's half 1, then the DMA pieces between the other MFMAs:
+    // the next step's weight pieces first, the activation pieces of step + SA - 1 after them
     NT3_READ(af0, bf0, sw0)
     mfma_range<0, NR>(acc, af1, bf1);
     NT3_IL(NR)
     __builtin_amdgcn_sched_barrier(0);
-    const bool epi_iter = ck == 0 && step > 0;
-    const bool all_p1 = MAE_NT3_SCHED == 0 || epi_iter || (MAE_NT3_SCHED == 2 && wave < 4);
-    const bool none_p1 = MAE_NT3_SCHED == 2 && !epi_iter && wave >= 4;
 #pragma unroll
     for (int q = 0; q < GPW; ++q) {
-      if (do_issue && (all_p1 || (!none_p1 && (q & 1) == 0))) issue_piece(q);
+      if (q < NW) { if (do_w) issue_w(q); }
+      else { if (do_a) issue_a(q - NW); }
+      if (q == NW - 1 && do_w) issue_bias();
 #pragma unroll
       for (int i = SP::lo(q); i < SP::hi(q); ++i) acc[i / NI][i % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i % NI], af1[i / NI], acc[i / NI][i % NI], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (do_issue && all_p1) issue_tail();
+#ifndef MAE_DBG_NT3_B3
+    if (do_w) stream_next(sw, SW);
+    if (do_a) stream_next(sa, SA);
+#else
+    sw.stage ^= 1; sa.stage = sa.stage == SA - 1 ? 0 : sa.stage + 1;
+#endif
     __builtin_amdgcn_sched_barrier(0);
 
+    NT3_TS(tc)
     // ---- a tile's first step: the previous tile is complete now
+#ifdef MAE_DBG_NT3_B4
+    if (false) {
+#else
     if (ck == 0 && step > 0) {
+#endif
       epilogue(p_m0, p_n0, p_strip);
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    NT3_TS(td)
     // ---- phase 2: reads of half 1 beside the MFMAs of half 0
     NT3_READ(af1, bf1, sw1)
     mfma_range<0, NR>(acc, af0, bf0);
     NT3_IL(NR)
-    if (MAE_NT3_SCHED == 0) {
-      mfma_range<NR, MI * NI>(acc, af0, bf0);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < GPW; ++q) {
-        if (do_issue && !all_p1 && (none_p1 || (q & 1) == 1)) issue_piece(q);
-#pragma unroll
-        for (int i = SP::lo(q); i < SP::hi(q); ++i) acc[i / NI][i % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0[i % NI], af0[i / NI], acc[i / NI][i % NI], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (do_issue && !all_p1) issue_tail();
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    mfma_range<NR, MI * NI>(acc, af0, bf0);
+    __builtin_amdgcn_sched_barrier(0);
 
-    cs = cs == NSTAGE - 1 ? 0 : cs + 1;
+    NT3_TS(te)
+#ifdef MAE_DBG_NT3_TRACE
+    tr_top += tb - ta; tr_p1 += tc - tb; tr_epi += td - tc; tr_p2 += te - td;
+#endif
+    csa = csa == SA - 1 ? 0 : csa + 1;
+    csw = csw == SW - 1 ? 0 : csw + 1;
     if (++ck == nk) {
       ck = 0;
       p_m0 = (int64_t)c_tm * BM; p_n0 = c_tn * BN; p_strip = ct & 1;
@@ -426,6 +457,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
   }
   mfma_range<0, MI * NI>(acc, af1, bf1);
   epilogue(p_m0, p_n0, p_strip);
+#ifdef MAE_DBG_NT3_TRACE
+  {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255) && lane == 0 && (wave == 0 || wave == 7))
+      printf("nt3 trace wg %d wave %d: M %d N %d K %d mode %d | %d tiles %d steps | clock %.2f GHz | cycles per step: total %d = wait+barrier %d + phase1 %d + epilogue %d (per tile %d) + phase2 %d\n",
+             (int)blockIdx.x, wave, (int)M, N, K, MODE, ntile, nsteps, (double)(t1 - tr_t0) / (double)(r1 - tr_r0) * 0.1, (int)((t1 - tr_t0) / nsteps), (int)(tr_top / nsteps),
+             (int)(tr_p1 / nsteps), (int)(tr_epi / nsteps), (int)(tr_epi / ntile), (int)(tr_p2 / nsteps));
+  }
+#endif
+#undef NT3_TS
 #undef NT3_READ
 #undef NT3_IL
 }

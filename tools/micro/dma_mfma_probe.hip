@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstdlib>
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -107,6 +108,8 @@ __global__ void __launch_bounds__(512, 2) probe(const u32x4* __restrict__ src, c
 //           step after next, and waits with vmcnt(4) at the top: the activation pieces have two steps to arrive from HBM
 //   mode 9  mode 7 with the activation pieces (4 of 7 per wave) streamed ONCE from a large buffer, each 32 KiB slice shared by 8
 //           workgroups of one XCD (equal blockIdx % 8) (first touch: HBM), weight pieces from the L2-resident window
+//   mode 13 mode 7 with the GEMM's source pattern, everything L2-resident: a piece is 8 rows x 128 B of a 448-row block at a 768-byte
+//           row pitch (K = 384), swizzled chunk order inside a row, the K-step selects the 128-byte column; 344 KiB block shared by all
 //   mode 11 / 12  modes 10 / 9 with the K order of a 6-step tile rotated by the workgroup's position among the 8 that share its slices:
 //           at any time the sharers ask for 6 different slices, a slice's first request pays HBM, the others find it in L2
 template <int MODE>
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(512, 2) kstep(const char* __restrict__ win, un
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
-  for (int i = tid; i < ((MODE == 10 || MODE == 11) ? 147456 : 2 * STAGE) / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0x3c003c00u, 0x3c00bc00u, 0x3c003c00u, 0xbc003c00u};
+  for (int i = tid; i < ((MODE == 10 || MODE == 11 || MODE == 14) ? 147456 : 2 * STAGE) / 16; i += 512) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0x3c003c00u, 0x3c00bc00u, 0x3c003c00u, 0xbc003c00u};
   __syncthreads();
   const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
   const uint64_t a = (uint64_t)(uintptr_t)win, b = (uint64_t)(uintptr_t)big;
@@ -135,7 +138,8 @@ __global__ void __launch_bounds__(512, 2) kstep(const char* __restrict__ win, un
   for (int j = 0; j < NI; ++j) bf1[j] = __builtin_bit_cast(bf16x8, u32x4{0, 0, 0, 0});
   const int sw0 = ((0 + fq) ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
   const int a_lane = (wm * 64 + fr) * 128, b_lane = 256 * 128 + (wn * 96 + fr) * 128;
-  const uint32_t voff = lane * 16;
+  const uint32_t r8_ = (uint32_t)lane >> 3;
+  const uint32_t voff = MODE == 13 ? r8_ * 768u + ((((uint32_t)lane & 7u) ^ r8_) << 4) : lane * 16;
   uint32_t pos = (uint32_t)wave * 7168u;
   // streamed activation slices: group = blockIdx / 8 ... 32 groups, each walks its own part of `big`
   const uint32_t big_part = big_bytes / 32u;
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(512, 2) kstep(const char* __restrict__ win, un
 #define MM(AF, BF, I0, I1) _Pragma("unroll") for (int i = (I0); i < (I1); ++i) acc[i / NI][i % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[i % NI], AF[i / NI], acc[i / NI][i % NI], 0, 0, 0);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int s = 0; s < steps; ++s) {
-    if (MODE == 10 || MODE == 11) {
+    if (MODE == 10 || MODE == 11 || MODE == 14) {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -163,8 +167,8 @@ __global__ void __launch_bounds__(512, 2) kstep(const char* __restrict__ win, un
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("" ::: "memory");
-    const char* stgA = (MODE == 10 || MODE == 11) ? smem + (s % 3) * 32768 : smem + cs * STAGE;
-    const char* stgB = (MODE == 10 || MODE == 11) ? smem + 98304 + cs * 24576 - 32768 : smem + cs * STAGE;
+    const char* stgA = (MODE == 10 || MODE == 11 || MODE == 14) ? smem + (s % 3) * 32768 : smem + cs * STAGE;
+    const char* stgB = (MODE == 10 || MODE == 11 || MODE == 14) ? smem + 98304 + cs * 24576 - 32768 : smem + cs * STAGE;
     RD(af0, bf0, sw0)
     MM(af1, bf1, 0, NR)
     IL(NR)
@@ -173,10 +177,13 @@ __global__ void __launch_bounds__(512, 2) kstep(const char* __restrict__ win, un
     for (int q = 0; q < 7; ++q) {
       if (MODE != 8) {
         const uint32_t dst = lds0 + (uint32_t)((cs ^ 1) * STAGE + wave * 7168 + q * 1024);
-        if (MODE == 10 || MODE == 11) {   // pieces 0-2: weights of the next step; pieces 3-6: activations of the step after next (ring of 3 x 32 KiB at 112 KiB)
+        if (MODE == 10 || MODE == 11 || MODE == 14) {   // pieces 0-2: weights of the next step; pieces 3-6: activations of the step after next (ring of 3 x 32 KiB at 112 KiB)
           if (q < 3) dma16(rs, lds0 + (uint32_t)(98304 + (cs ^ 1) * 24576 + (wave * 3 + q) * 1024), voff, pos + q * 1024u);
+          else if (MODE == 14) dma16(rs, lds0 + (uint32_t)(((s + 2) % 3) * 32768 + (wave * 4 + q - 3) * 1024), voff, pos + q * 1024u);
           else dma16(rb, lds0 + (uint32_t)(((s + 2) % 3) * 32768 + (wave * 4 + q - 3) * 1024), voff, bpos + (q - 3) * 1024u);
         } else if ((MODE == 9 || MODE == 12) && q < 4) dma16(rb, dst, voff, bpos + q * 1024u);
+        else if (MODE == 15) { if (s + 1 < steps) dma16(rs, dst, voff, pos + q * 1024u); }
+        else if (MODE == 13) dma16(rs, dst, voff, (uint32_t)((wave * 7 + q) * 8) * 768u + (uint32_t)(s % 6) * 128u);
         else dma16(rs, dst, voff, pos + q * 1024u);
       }
       MM(af1, bf1, NR + 2 * q, NR + 2 * q + 2)
@@ -221,7 +228,14 @@ int main() {
   u32x4* src; float* out; char* win; unsigned long long* ticks;
   const unsigned win_bytes = 2u << 20;   // 2 MiB: stays in every XCD's L2
   hipMalloc(&src, h.size() * 4); hipMalloc(&out, wgs * 512 * 4); hipMalloc(&win, win_bytes); hipMalloc(&ticks, wgs * 8 * 2 * 8);
-  hipMemset(win, 0x3c, win_bytes);
+  {
+    std::vector<unsigned> hw(win_bytes / 4);
+    unsigned y = 777;
+    const bool rnd = getenv("PROBE_RANDOM") != nullptr;
+    for (auto& w : hw) { y = y * 1664525u + 1013904223u; w = rnd ? ((y & 0xbf80bf80u) | 0x3c003c00u) : 0x3c3c3c3cu; }
+    hipMemcpy(win, hw.data(), win_bytes, hipMemcpyHostToDevice);
+    printf("window data: %s\n", rnd ? "random bf16" : "constant");
+  }
   hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   auto run = [&](int mode) {
     auto launch = [&] {
@@ -267,6 +281,10 @@ int main() {
         case 9: hipLaunchKernelGGL(kstep<9>, dim3(wgs), dim3(512), 2 * 57344, 0, win, win_bytes, big, big_bytes, out, ticks, steps); break;
         case 11: hipFuncSetAttribute((const void*)kstep<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
                  hipLaunchKernelGGL(kstep<11>, dim3(wgs), dim3(512), 147456, 0, win, win_bytes, big, big_bytes, out, ticks, steps); break;
+        case 14: hipFuncSetAttribute((const void*)kstep<14>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+                 hipLaunchKernelGGL(kstep<14>, dim3(wgs), dim3(512), 147456, 0, win, win_bytes, big, big_bytes, out, ticks, steps); break;
+        case 15: hipLaunchKernelGGL(kstep<15>, dim3(wgs), dim3(512), 2 * 57344, 0, win, win_bytes, big, big_bytes, out, ticks, steps); break;
+        case 13: hipLaunchKernelGGL(kstep<13>, dim3(wgs), dim3(512), 2 * 57344, 0, win, win_bytes, big, big_bytes, out, ticks, steps); break;
         case 12: hipLaunchKernelGGL(kstep<12>, dim3(wgs), dim3(512), 2 * 57344, 0, win, win_bytes, big, big_bytes, out, ticks, steps); break;
         default: hipFuncSetAttribute((const void*)kstep<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
                  hipLaunchKernelGGL(kstep<10>, dim3(wgs), dim3(512), 147456, 0, win, win_bytes, big, big_bytes, out, ticks, steps); break;
@@ -280,10 +298,10 @@ int main() {
     hipMemcpy(t.data(), ticks, t.size() * 8, hipMemcpyDeviceToHost);
     double mt = 0, rt = 0;
     for (size_t i = 0; i < t.size(); i += 2) { mt += (double)t[i]; rt += (double)t[i + 1]; }
-    const char* names[7] = {"reads + MFMAs + pieces, no barrier", "+ vmcnt(0) + barrier per step", "reads + MFMAs + barrier, no pieces", "as 7, activation pieces first-touch (HBM)", "as 9, activation ring 3 deep (2 steps ahead)", "as 10 + K order rotated among the sharers", "as 9 + K order rotated among the sharers"};
+    const char* names[10] = {"reads + MFMAs + pieces, no barrier", "+ vmcnt(0) + barrier per step", "reads + MFMAs + barrier, no pieces", "as 7, activation pieces first-touch (HBM)", "as 9, activation ring 3 deep (2 steps ahead)", "as 10 + K order rotated among the sharers", "as 9 + K order rotated among the sharers", "as 7, GEMM source pattern (768-B pitch), L2-resident", "as 10, every piece from the L2 window", "as 7, a uniform branch around every piece"};
     printf("mode %d %-42s: %8.3f ms | %5.0f ns per step | %6.0f TFLOP/s | %.2f GHz\n", mode, names[mode - 6], ms, ms * 1e6 / steps,
            2.0 * 256 * 192 * 64 * (double)steps * wgs / ms / 1e9, mt / rt * 0.1);
   };
-  for (int m : {8, 7, 9, 10, 12, 11, 9, 10, 12, 11}) run2(m);
+  for (int m : {8, 7, 15, 14, 7, 15, 14}) run2(m);
   return 0;
 }
