@@ -138,7 +138,8 @@ int launch_linear_fwd(const void* A, const void* W, int64_t M, int N, int K, int
   MAE_TRY(check_epi(e, dt, "linear_fwd"));
   if (dt == MAE_BF16) {
     const char* var = getenv("MAE_GEMM_NT");  // "v1" pins the per-tile kernel, "v2" round 2's ring kernel (A/B runs in tools/gemm_bench.py)
-    if (var && var[0] == 'v' && var[1] == '3') {
+    const bool pin = var && var[0] == 'v' && (var[1] == '1' || var[1] == '2');
+    if (!pin) {   // round 3's K-loop (k_gemm_nt3.hip) wherever it applies; v2 keeps the epilogues the engine does not use
       const int r3 = mfma_linear_fwd_v3((const bf16*)A, (const bf16*)W, M, N, K, e, s);
       if (r3 != MFMA_UNSUPPORTED) return r3;
     }

@@ -10,25 +10,25 @@
 //     with its 7 DMA pieces per wave, counted wait and barrier runs at 760 ns = 2.1 PFLOP/s when every piece hits L2.
 //   * it does not when the activation rows are first touched in HBM one step before they are needed: 1300 ns.  A tile's row
 //     panel is new to the chip, the tiles_n workgroups that share it (same XCD) ask for the same slice at the same time, and a
-//     two-stage ring has one step of lookahead: every step of every sharer waits for HBM.  Two changes, both measured in the
-//     probe (1300 -> 960 -> 880 ns):
+//     two-stage ring has one step of lookahead: every step of every sharer waits for HBM (probe: 1300 -> 960 ns with):
 //       - SPLIT RINGS: weight rows always hit L2 (one step of lookahead is enough: 2 stages), so the LDS the third stage of a
 //         uniform ring would need goes to the activation rows alone: 3 x 32 KiB (256-row tiles) or 4 x 24 KiB (192-row tiles),
 //         two / three steps of lookahead.  A wave issues its weight pieces first and its activation pieces after them, so
 //         that the in-order vmcnt can wait for the young weight pieces while the younger activation pieces stay in flight.
-//       - ROTATED K ORDER: the sharers of a panel walk its K-steps from different starting points ((k + rot(tn)) mod nk), so
-//         that at any time they ask for different slices: a slice's first request pays HBM, the other sharers find it in L2.
-//         (The per-element summation order over K therefore depends on the tile column; deterministic, not bit-equal to v2.
-//         -DMAE_NT3_NOROT keeps K ascending: that build is bit-identical to v2, tools/gemm_bench.py.)
 //   * a DMA piece is `s_mov m0` + ONE `buffer_load_dwordx4 ... lds` whose per-lane offset never changes (row-in-group x row pitch
 //     + swizzled chunk) and whose tile / group / K-step position is a scalar offset; rows past M need no clamp (the buffer
 //     descriptor's range check returns zeros); pieces go out one at a time between pairs of MFMAs, all of them in the first
 //     half of a step (before the epilogue's stores, which the counted waits then allow to stay in flight).
-//   Tried and dropped (same file): an L2 prefetch of the NEXT tile's panel by 4-byte-per-lane DMAs (a whole tile ahead it thrashes
+//   * the scalar bookkeeping of a step (stream positions, stage pointers, which wait applies) used to sit between the barrier and
+//     the first MFMA, on every wave's critical path: now a tile's K-steps are an inner loop whose waits are fixed, the tile switch
+//     happens in a peeled first step, and the position updates sit in the shadow of phase 2's MFMAs.
+//   Tried and dropped (same file): a K order rotated by the tile column so that the sharers of a row panel ask for different
+//   slices (880 ns in the probe, nothing in the kernel, and the summation order would depend on the column), an L2 prefetch of the NEXT tile's panel by 4-byte-per-lane DMAs (a whole tile ahead it thrashes
 //   L2 on the narrow-N shapes and costs as many tag lookups as half the pieces: 5-10 % slower), pieces spread over both halves of
 //   a step or issued by the two waves of a SIMD in different halves (2-5 % slower).
 #include "gemm_mfma.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace mae {
 
@@ -36,19 +36,27 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int BK3 = 64;
-template <int NI, int MI>
+// WM = waves along M (2 waves along N).  WM = 4: one 512-thread workgroup per CU (256- or 192-row tiles, all 160 KiB of LDS).
+// WM = 2: 256-thread workgroups, two per CU (128-row tiles, 80 KiB each): two independent wave groups share every SIMD, so one
+// group's epilogue (VALU + stores) can run beside the other group's K-loop (matrix pipe); no LDS left for the bias strips
+// (the epilogue reads the bias from L2).
+template <int NI, int MI, int WM>
 struct Geo3 {
-  static constexpr int BN = 32 * NI, BM = 64 * MI;
+  static constexpr int NWV = 2 * WM;                                  // waves per workgroup
+  static constexpr int BN = 32 * NI, BM = 16 * MI * WM;
   static constexpr int ASTG = BM * BK3 * 2, WSTG = BN * BK3 * 2;      // one K-step of activation rows / of weight rows, 128 B per row
-  static constexpr int TAIL = 2 * BN * 4;                             // bias strips of two tiles
+  static constexpr int CAP = WM == 4 ? 160 * 1024 : 80 * 1024;
+  static constexpr bool STRIP = WM == 4;                              // bias strips of two tiles in LDS
+  static constexpr int TAIL = STRIP ? 2 * BN * 4 : 0;
   static constexpr int SW = 2;                                        // weight ring: L2 hits, one step ahead
-  static constexpr int SA = (160 * 1024 - TAIL - SW * WSTG) / ASTG >= 4 ? 4 : 3;   // activation ring: 2 or 3 steps ahead
+  static constexpr int SA_ = (CAP - TAIL - SW * WSTG) / ASTG;
+  static constexpr int SA = SA_ >= 4 ? 4 : SA_;                       // activation ring: 1 to 3 steps ahead
   static constexpr int A_OFF = 0, W_OFF = SA * ASTG, BIAS_OFF = W_OFF + SW * WSTG;
   static constexpr int LDS = BIAS_OFF + TAIL;
-  static constexpr int NA = BM / 64, NW = BN / 64;                    // 1 KiB DMA pieces (8 rows) per wave and step: activation, weight
+  static constexpr int NA = BM / 8 / NWV, NW = BN / 8 / NWV;          // 1 KiB DMA pieces (8 rows) per wave and step: activation, weight
   static constexpr int GPW = NA + NW;
   static constexpr int NBIAS = BN / 64;
-  static_assert(LDS <= 160 * 1024 && BM % 64 == 0 && BN % 64 == 0, "LDS budget / even deal of the pieces over the 8 waves");
+  static_assert(SA >= 2 && LDS <= CAP && BM % (8 * NWV) == 0 && BN % (8 * NWV) == 0, "LDS budget / even deal of the pieces over the waves");
 };
 
 __device__ __forceinline__ void unpack8(const bf16x8& v, f32x4& a, f32x4& b) {
@@ -122,11 +130,11 @@ struct Spread {
 
 }  // namespace
 
-template <int MODE, class TO, bool HAS_BIAS, int NI, int MI>
-__global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M, int N, int K,
-                                                          const float* __restrict__ bias, const void* __restrict__ aux, TO* __restrict__ out,
-                                                          TO* __restrict__ out2, int tiles_m, int tiles_n) {
-  using G_ = Geo3<NI, MI>;
+template <int MODE, class TO, bool HAS_BIAS, int NI, int MI, int WM>
+__global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M, int N, int K,
+                                                               const float* __restrict__ bias, const void* __restrict__ aux, TO* __restrict__ out,
+                                                               TO* __restrict__ out2, int tiles_m, int tiles_n) {
+  using G_ = Geo3<NI, MI, WM>;
   using SP = Spread<MI, NI, G_::GPW>;
   constexpr int BM = G_::BM, BN = G_::BN, ASTG = G_::ASTG, WSTG = G_::WSTG, SA = G_::SA, SW = G_::SW, NA = G_::NA, NW = G_::NW, GPW = G_::GPW;
   constexpr int NJ = NI / 2, NR = MI + NI;
@@ -134,6 +142,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
   constexpr int STORE8 = sizeof(TO) == 2 ? 1 : 2;          // store instructions per 8 outputs
   constexpr int E = MI * NJ * STORE8 * (TWO ? 2 : 1);      // epilogue stores per wave (full tile)
   static_assert(SW == 2, "the waits below assume weight pieces one step ahead");
+  constexpr int NAF = SA > 2 ? NA : 0;                      // activation pieces that stay in flight across a step's wait
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,12 +153,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
   const int vb = (int)xcd_remap3(blockIdx.x, G);
   const int ntile = (T - vb + G - 1) / G;
   const int nk = K / BK3;
-  const int nsteps = ntile * nk;
   const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
   const uint32_t rowbytes = (uint32_t)K * 2u;
 
   // ---- producer side: two DMA streams (weight rows one step ahead, activation rows SA - 1 steps ahead), all scalar but two
-  // per-lane offsets that never change.  Every wave owns NA activation pieces and NW weight pieces of a step.
+  // per-lane offsets that never change.  Every wave owns NA activation pieces and NW weight pieces of a step.  The streams are
+  // never switched off: past the last tile they fetch rows that do not exist (the descriptor's range check turns those into
+  // zeros, or the 32-bit offset wraps onto valid rows) into stages nobody reads any more, which keeps every step's count of
+  // vector-memory operations, and with it every wait, the same.
   const i32x4 rsA = make_rsrc(A, (uint32_t)((uint64_t)M * rowbytes));
   const i32x4 rsW = make_rsrc(W, (uint32_t)N * rowbytes);
   const i32x4 rsB = make_rsrc(bias, HAS_BIAS ? (uint32_t)N * 4u : 0u);
@@ -157,55 +168,51 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
   const uint32_t voff = r8 * rowbytes + ((((uint32_t)lane & 7u) ^ r8) << 4);   // row r8 of an 8-row piece, swizzled source chunk for LDS slot lane & 7
   const uint32_t voff_b = (uint32_t)lane * 4u;
   const int dq = G / tiles_n, dr = G % tiles_n;            // tile id + G in (row, column) form, without a division per tile
-  // K order of a tile, rotated by its column so that the tiles_n workgroups sharing a row panel ask for different slices
-#ifdef MAE_NT3_NOROT
-  const int rot_mul = 0;
-#else
-  const int rot_mul = nk >= tiles_n ? nk / tiles_n : 1;
-#endif
-  struct Stream { int tm, tn, k, kk, tile, stage; };       // tile (row, column), step inside it, rotated K index, tile ordinal, ring stage
-  auto stream_init = [&](Stream& st) { st.tm = vb / tiles_n; st.tn = vb % tiles_n; st.k = 0; st.kk = (st.tn * rot_mul) % nk; st.tile = 0; st.stage = 0; };
-  auto stream_next = [&](Stream& st, int nstage) {
-    st.stage = st.stage == nstage - 1 ? 0 : st.stage + 1;
-    st.kk = st.kk == nk - 1 ? 0 : st.kk + 1;
-    if (++st.k == nk) {
-      st.k = 0; ++st.tile;
-      st.tm += dq; st.tn += dr;
-      if (st.tn >= tiles_n) { st.tn -= tiles_n; ++st.tm; }
-      st.kk = (st.tn * rot_mul) % nk;
-    }
-  };
+  struct Stream { int tm, tn, k, tile; uint32_t base, lds; };   // tile (row, column), K-step inside it, tile ordinal; scalar source offset and LDS address of the step
   Stream sa, sw;
-  stream_init(sa); stream_init(sw);
-  auto issue_a = [&](int q) {   // activation piece q of this wave: rows 8 (wave NA + q) .. + 7 of the panel
-    const int g = wave * NA + q;
+  sa.tm = sw.tm = vb / tiles_n; sa.tn = sw.tn = vb % tiles_n; sa.k = sw.k = 0; sa.tile = sw.tile = 0;
+  sa.base = ((uint32_t)sa.tm * BM + (uint32_t)(wave * NA * 8)) * rowbytes;   // this wave's first activation piece of the step
+  sw.base = ((uint32_t)sw.tn * BN + (uint32_t)(wave * NW * 8)) * rowbytes;
+  sa.lds = lds0 + (uint32_t)(G_::A_OFF + wave * NA * 1024);
+  sw.lds = lds0 + (uint32_t)(G_::W_OFF + wave * NW * 1024);
+  const uint32_t piece = 8u * rowbytes;
+  auto issue_a = [&](int q) {
 #ifndef MAE_DBG_NO_DMA
-#if defined(MAE_DBG_NT3_ONLY_W)
-#elif defined(MAE_DBG_NT3_DMA_FIXED)   // timing probes, wrong values: every piece reads the same KiB (L1-resident) ...
-    dma16(rsA, lds0 + (uint32_t)(G_::A_OFF + sa.stage * ASTG + g * 1024), (uint32_t)lane * 16u, (uint32_t)wave * 1024u);
-#elif defined(MAE_DBG_NT3_A_RESIDENT)   // ... every tile reads the first row panel (L2-resident after its first use)
-    dma16(rsA, lds0 + (uint32_t)(G_::A_OFF + sa.stage * ASTG + g * 1024), voff, ((uint32_t)(g * 8)) * rowbytes + (uint32_t)sa.kk * 128u);
-#else
-    dma16(rsA, lds0 + (uint32_t)(G_::A_OFF + sa.stage * ASTG + g * 1024), voff, ((uint32_t)sa.tm * BM + (uint32_t)(g * 8)) * rowbytes + (uint32_t)sa.kk * 128u);
-#endif
+    dma16(rsA, sa.lds + (uint32_t)(q * 1024), voff, sa.base + (uint32_t)q * piece);
 #endif
   };
   auto issue_w = [&](int q) {
-    const int g = wave * NW + q;
-#if defined(MAE_DBG_NO_DMA) || defined(MAE_DBG_NT3_ONLY_A)
-#elif defined(MAE_DBG_NT3_DMA_FIXED)
-    dma16(rsW, lds0 + (uint32_t)(G_::W_OFF + sw.stage * WSTG + g * 1024), (uint32_t)lane * 16u, (uint32_t)wave * 1024u);
-#else
-    dma16(rsW, lds0 + (uint32_t)(G_::W_OFF + sw.stage * WSTG + g * 1024), voff, ((uint32_t)sw.tn * BN + (uint32_t)(g * 8)) * rowbytes + (uint32_t)sw.kk * 128u);
+#ifndef MAE_DBG_NO_DMA
+    dma16(rsW, sw.lds + (uint32_t)(q * 1024), voff, sw.base + (uint32_t)q * piece);
 #endif
   };
   auto issue_bias = [&]() {     // the tile's bias strip rides with the weight pieces of its first step (every wave writes the same bytes)
 #ifndef MAE_DBG_NO_DMA
-    if (HAS_BIAS && sw.k == 0) {
+    if (HAS_BIAS && G_::STRIP && sw.k == 0) {
 #pragma unroll
       for (int i = 0; i < G_::NBIAS; ++i) dma4(rsB, lds0 + (uint32_t)(G_::BIAS_OFF + (sw.tile & 1) * (BN * 4) + 256 * i), voff_b, (uint32_t)(sw.tn * BN * 4 + 256 * i));
     }
 #endif
+  };
+  auto next_a = [&]() {
+    sa.base += 128u;
+    sa.lds = sa.lds == lds0 + (uint32_t)(G_::A_OFF + (SA - 1) * ASTG + wave * NA * 1024) ? lds0 + (uint32_t)(G_::A_OFF + wave * NA * 1024) : sa.lds + (uint32_t)ASTG;
+    if (++sa.k == nk) {
+      sa.k = 0; ++sa.tile;
+      sa.tm += dq; sa.tn += dr;
+      if (sa.tn >= tiles_n) { sa.tn -= tiles_n; ++sa.tm; }
+      sa.base = ((uint32_t)sa.tm * BM + (uint32_t)(wave * NA * 8)) * rowbytes;
+    }
+  };
+  auto next_w = [&]() {
+    sw.base += 128u;
+    sw.lds = sw.lds == lds0 + (uint32_t)(G_::W_OFF + (SW - 1) * WSTG + wave * NW * 1024) ? lds0 + (uint32_t)(G_::W_OFF + wave * NW * 1024) : sw.lds + (uint32_t)WSTG;
+    if (++sw.k == nk) {
+      sw.k = 0; ++sw.tile;
+      sw.tm += dq; sw.tn += dr;
+      if (sw.tn >= tiles_n) { sw.tn -= tiles_n; ++sw.tm; }
+      sw.base = ((uint32_t)sw.tn * BN + (uint32_t)(wave * NW * 8)) * rowbytes;
+    }
   };
 
   f32x4 acc[MI][NI];
@@ -225,25 +232,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
 
   // prologue: activation steps 0 .. SA - 2, then weight step 0 (the youngest: the first wait drains everything)
 #pragma unroll
-  for (int a = 0; a < SA - 1; ++a)
-    if (a < nsteps) {
+  for (int a = 0; a < SA - 1; ++a) {
 #pragma unroll
-      for (int q = 0; q < NA; ++q) issue_a(q);
-      stream_next(sa, SA);
-    }
+    for (int q = 0; q < NA; ++q) issue_a(q);
+    next_a();
+  }
 #pragma unroll
   for (int q = 0; q < NW; ++q) issue_w(q);
   issue_bias();
-  stream_next(sw, SW);
+  next_w();
 
   // ---- consumer side
   const int sw0 = ((0 + fq) ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
   const int gb = (fq & 1) ? 3 + fq : fq;
-  const int a_lane = G_::A_OFF + (wm * WROWS + fr) * 128, b_lane = G_::W_OFF + (wn * (NI * 16) + fr) * 128;
+  const char* rd_a = smem + G_::A_OFF + (wm * WROWS + fr) * 128;            // this lane's fragment rows in the current stages
+  const char* rd_w = smem + G_::W_OFF + (wn * (NI * 16) + fr) * 128;
+  const char* const rd_a_last = smem + G_::A_OFF + (SA - 1) * ASTG + (wm * WROWS + fr) * 128;
+  const char* const rd_w_last = smem + G_::W_OFF + (SW - 1) * WSTG + (wn * (NI * 16) + fr) * 128;
   int c_tm = vb / tiles_n, c_tn = vb % tiles_n;   // tile being multiplied
-  int64_t p_m0 = 0;                               // tile whose epilogue is pending
-  int p_n0 = 0, p_strip = 0;
-  int ct = 0, ck = 0, csa = 0, csw = 0;
   bool prev_full = false;
 
   auto epilogue = [&](int64_t m0, int n0, int strip) {
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
           acc[mi][2 * j][r] = __uint_as_float(sw[0]);
           acc[mi][2 * j + 1][r] = __uint_as_float(sw[1]);
         }
-    const float* sbias = reinterpret_cast<const float*>(smem + G_::BIAS_OFF + strip * (BN * 4)) + wn * (NI * 16);
+    const float* sbias = G_::STRIP ? reinterpret_cast<const float*>(smem + G_::BIAS_OFF + strip * (BN * 4)) + wn * (NI * 16) : bias + n0 + wn * (NI * 16);
     const int colw = n0 + wn * (NI * 16) + 4 * gb;      // this lane's column inside group 0
 #ifndef MAE_DBG_NO_EPI
     if constexpr (sizeof(TO) == 2) {
@@ -348,144 +354,100 @@ __global__ void __launch_bounds__(512, 2) gemm_nt3_kernel(const bf16* __restrict
   };
 
 
+
 #define NT3_READ(AF, BF, SWZ)                                                                                      \
   {                                                                                                                \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) AF[mi] = *reinterpret_cast<const bf16x8*>(stg_a + a_lane + mi * 2048 + (SWZ)); \
-    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) BF[ni] = *reinterpret_cast<const bf16x8*>(stg_w + b_lane + ni * 2048 + (SWZ)); \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) AF[mi] = *reinterpret_cast<const bf16x8*>(rd_a + mi * 2048 + (SWZ)); \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) BF[ni] = *reinterpret_cast<const bf16x8*>(rd_w + ni * 2048 + (SWZ)); \
   }
 #define NT3_IL(n)                                              \
   _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {        \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         \
   }
-
-#ifdef MAE_DBG_NT3_TRACE   // cycle breakdown of a step (alternate build; prints from three workgroups, perturbs the timing a little)
-  unsigned long long tr_top = 0, tr_p1 = 0, tr_epi = 0, tr_p2 = 0;
-  const unsigned long long tr_t0 = __builtin_amdgcn_s_memtime(), tr_r0 = __builtin_amdgcn_s_memrealtime();
-#define NT3_TS(var) { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define NT3_TS(var)
-#endif
-  for (int step = 0; step < nsteps; ++step) {
-#ifdef MAE_DBG_NT3_TRACE
-    unsigned long long ta, tb, tc, td, te;
-#endif
-    NT3_TS(ta)
-    // ---- wait for this step's weight pieces (issued in the previous iteration; everything older, the step's activation pieces
-    // included, has retired by then).  Younger, and allowed to stay in flight: the activation pieces issued after them in that
-    // iteration, and the stores of an epilogue that ran there (counted only when that tile was full: every store was issued).
-    {
-      const bool a_prev = step > 0 && step + SA - 2 < nsteps;               // the previous iteration issued activation pieces
-      const bool epi1 = ck == 1 && ct > 0 && prev_full;                      // ... and ran an epilogue
-#ifdef MAE_DBG_NT3_B1   // bisection builds (timing only)
-      wait_vm3<0>();
-#else
-      if (a_prev && epi1) wait_vm3<NA + E>();
-      else if (a_prev) wait_vm3<NA>();
-      else if (epi1) wait_vm3<E>();
-      else wait_vm3<0>();
-#endif
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the stages refilled below have landed in its registers
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+  // One K-step.  Top: wait for this step's weight pieces (issued in the previous step; everything older, the step's activation
+  // pieces included, has retired by then), make every wave's reads of the stages refilled below land, barrier.
+  // Phase 1: reads of half 0 beside the MFMAs of the previous step's half 1, then the DMA pieces between the other MFMAs: the
+  // next step's weight pieces first, the activation pieces of step + SA - 1 after them.  Phase 2: reads of half 1 beside the
+  // MFMAs of half 0; the scalar bookkeeping of the next step sits in its shadow.
+#define NT3_STEP_TOP(NVM)                                                                                          \
+    wait_vm3<NVM>();                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+    __builtin_amdgcn_s_barrier();                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
     asm volatile("" ::: "memory");
-    const char* stg_a = smem + csa * ASTG;
-    const char* stg_w = smem + csw * WSTG;
-#ifdef MAE_DBG_NT3_B2
-    const bool do_w = true, do_a = true;
-#else
-    const bool do_w = step + 1 < nsteps, do_a = step + SA - 1 < nsteps;
-#endif
-    NT3_TS(tb)
-
-    // ---- phase 1: reads of half 0 beside the MFMAs of the previous step's half 1, then the DMA pieces between the other MFMAs:
-    // the next step's weight pieces first, the activation pieces of step + SA - 1 after them
-    NT3_READ(af0, bf0, sw0)
-    mfma_range<0, NR>(acc, af1, bf1);
-    NT3_IL(NR)
+#define NT3_PHASE1()                                                                                               \
+    NT3_READ(af0, bf0, sw0)                                                                                        \
+    mfma_range<0, NR>(acc, af1, bf1);                                                                              \
+    NT3_IL(NR)                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int q = 0; q < GPW; ++q) {                                                              \
+      if (q < NW) issue_w(q); else issue_a(q - NW);                                                                \
+      if (q == NW - 1) issue_bias();                                                                               \
+      _Pragma("unroll") for (int i = SP::lo(q); i < SP::hi(q); ++i)                                                \
+        acc[i / NI][i % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i % NI], af1[i / NI], acc[i / NI][i % NI], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+    }
+#define NT3_PHASE2()                                                                                               \
+    NT3_READ(af1, bf1, sw1)                                                                                        \
+    mfma_range<0, NR>(acc, af0, bf0);                                                                              \
+    NT3_IL(NR)                                                                                                     \
+    next_w(); next_a();                                                                                            \
+    rd_a = rd_a == rd_a_last ? rd_a - (SA - 1) * ASTG : rd_a + ASTG;                                               \
+    rd_w = rd_w == rd_w_last ? rd_w - (SW - 1) * WSTG : rd_w + WSTG;                                               \
+    mfma_range<NR, MI * NI>(acc, af0, bf0);                                                                        \
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < GPW; ++q) {
-      if (q < NW) { if (do_w) issue_w(q); }
-      else { if (do_a) issue_a(q - NW); }
-      if (q == NW - 1 && do_w) issue_bias();
-#pragma unroll
-      for (int i = SP::lo(q); i < SP::hi(q); ++i) acc[i / NI][i % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i % NI], af1[i / NI], acc[i / NI][i % NI], 0, 0, 0);
+
+  for (int tile = 0; tile < ntile; ++tile) {
+    // ---- a tile's first step: the previous tile is completed by phase 1 and stored before phase 2
+    // (outstanding at the wait: the activation pieces issued after the awaited weight pieces in the previous step)
+    if (tile == 0) { NT3_STEP_TOP(0) } else { NT3_STEP_TOP(NAF) }
+    NT3_PHASE1()
+    if (tile > 0) {
+      const int p_tm = c_tm - dq - (c_tn - dr < 0 ? 1 : 0), p_tn = c_tn - dr < 0 ? c_tn - dr + tiles_n : c_tn - dr;
+      epilogue((int64_t)p_tm * BM, p_tn * BN, (tile - 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-#ifndef MAE_DBG_NT3_B3
-    if (do_w) stream_next(sw, SW);
-    if (do_a) stream_next(sa, SA);
-#else
-    sw.stage ^= 1; sa.stage = sa.stage == SA - 1 ? 0 : sa.stage + 1;
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-
-    NT3_TS(tc)
-    // ---- a tile's first step: the previous tile is complete now
-#ifdef MAE_DBG_NT3_B4
-    if (false) {
-#else
-    if (ck == 0 && step > 0) {
-#endif
-      epilogue(p_m0, p_n0, p_strip);
-      __builtin_amdgcn_sched_barrier(0);
+    NT3_PHASE2()
+    // ---- the other steps; at the second one the epilogue's stores (counted only when that tile was full: every store was issued)
+    // may stay in flight too
+    const bool stores = tile > 0 && prev_full;
+    for (int k = 1; k < nk; ++k) {
+      if (k == 1 && stores) { NT3_STEP_TOP(NAF + E) } else { NT3_STEP_TOP(NAF) }
+      NT3_PHASE1()
+      NT3_PHASE2()
     }
-
-    NT3_TS(td)
-    // ---- phase 2: reads of half 1 beside the MFMAs of half 0
-    NT3_READ(af1, bf1, sw1)
-    mfma_range<0, NR>(acc, af0, bf0);
-    NT3_IL(NR)
-    mfma_range<NR, MI * NI>(acc, af0, bf0);
-    __builtin_amdgcn_sched_barrier(0);
-
-    NT3_TS(te)
-#ifdef MAE_DBG_NT3_TRACE
-    tr_top += tb - ta; tr_p1 += tc - tb; tr_epi += td - tc; tr_p2 += te - td;
-#endif
-    csa = csa == SA - 1 ? 0 : csa + 1;
-    csw = csw == SW - 1 ? 0 : csw + 1;
-    if (++ck == nk) {
-      ck = 0;
-      p_m0 = (int64_t)c_tm * BM; p_n0 = c_tn * BN; p_strip = ct & 1;
-      ++ct;
-      c_tm += dq; c_tn += dr;
-      if (c_tn >= tiles_n) { c_tn -= tiles_n; ++c_tm; }
-    }
+    c_tm += dq; c_tn += dr;
+    if (c_tn >= tiles_n) { c_tn -= tiles_n; ++c_tm; }
   }
   mfma_range<0, MI * NI>(acc, af1, bf1);
-  epilogue(p_m0, p_n0, p_strip);
-#ifdef MAE_DBG_NT3_TRACE
   {
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if ((blockIdx.x == 0 || blockIdx.x == 100 || blockIdx.x == 255) && lane == 0 && (wave == 0 || wave == 7))
-      printf("nt3 trace wg %d wave %d: M %d N %d K %d mode %d | %d tiles %d steps | clock %.2f GHz | cycles per step: total %d = wait+barrier %d + phase1 %d + epilogue %d (per tile %d) + phase2 %d\n",
-             (int)blockIdx.x, wave, (int)M, N, K, MODE, ntile, nsteps, (double)(t1 - tr_t0) / (double)(r1 - tr_r0) * 0.1, (int)((t1 - tr_t0) / nsteps), (int)(tr_top / nsteps),
-             (int)(tr_p1 / nsteps), (int)(tr_epi / nsteps), (int)(tr_epi / ntile), (int)(tr_p2 / nsteps));
+    const int p_tm = c_tm - dq - (c_tn - dr < 0 ? 1 : 0), p_tn = c_tn - dr < 0 ? c_tn - dr + tiles_n : c_tn - dr;
+    epilogue((int64_t)p_tm * BM, p_tn * BN, (ntile - 1) & 1);
   }
-#endif
-#undef NT3_TS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the phantom pieces issued past the last tile land before the LDS is released
+#undef NT3_PHASE2
+#undef NT3_PHASE1
+#undef NT3_STEP_TOP
 #undef NT3_READ
 #undef NT3_IL
 }
 
-template <int MODE, class TO, int NI, int MI>
+template <int MODE, class TO, int NI, int MI, int WM>
 static int launch_nt3(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
-  using G_ = Geo3<NI, MI>;
+  using G_ = Geo3<NI, MI, WM>;
   const int64_t T = cdiv(M, G_::BM) * (N / G_::BN);
   MAE_REQUIRE(T < (1ll << 30), "gemm: too many tiles");
   const int tiles_m = (int)cdiv(M, G_::BM), tiles_n = N / G_::BN;
-  const int grid = (int)std::min<int64_t>(T, num_cus());  // one persistent workgroup per CU
+  const int grid = (int)std::min<int64_t>(T, (int64_t)num_cus() * (WM == 4 ? 1 : 2));  // persistent: one 8-wave or two 4-wave workgroups per CU
   if (e.bias) {
-    auto kern = gemm_nt3_kernel<MODE, TO, true, NI, MI>;
+    auto kern = gemm_nt3_kernel<MODE, TO, true, NI, MI, WM>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
   } else {
-    auto kern = gemm_nt3_kernel<MODE, TO, false, NI, MI>;
+    auto kern = gemm_nt3_kernel<MODE, TO, false, NI, MI, WM>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
   }
   MAE_LAUNCH_CHECK();
   return 0;
@@ -503,11 +465,15 @@ static bool prefer_bm192_3(int64_t M, int N) {
 
 template <int MODE, class TO>
 static int launch_nt3_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
+  const char* var = getenv("MAE_GEMM_NT");   // A/B: "v3w2" = two 4-wave workgroups per CU on 128-row tiles
+  const bool w2 = var && strstr(var, "w2") != nullptr;
   if (N % 192 == 0) {
-    if (prefer_bm192_3(M, N)) return launch_nt3<MODE, TO, 6, 3>(A, W, M, N, K, e, s);
-    return launch_nt3<MODE, TO, 6, 4>(A, W, M, N, K, e, s);
+    if (w2) return launch_nt3<MODE, TO, 6, 4, 2>(A, W, M, N, K, e, s);
+    if (prefer_bm192_3(M, N)) return launch_nt3<MODE, TO, 6, 3, 4>(A, W, M, N, K, e, s);
+    return launch_nt3<MODE, TO, 6, 4, 4>(A, W, M, N, K, e, s);
   }
-  return launch_nt3<MODE, TO, 4, 4>(A, W, M, N, K, e, s);
+  if (w2) return launch_nt3<MODE, TO, 4, 4, 2>(A, W, M, N, K, e, s);
+  return launch_nt3<MODE, TO, 4, 4, 4>(A, W, M, N, K, e, s);
 }
 
 int mfma_linear_fwd_v3(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {

@@ -28,6 +28,12 @@ SHAPES = [  # name, M, N, K, epilogue, out dtype
     ("dec qkv fwd", 290000, 576, 192, "none", BF16),
     ("dec fc1 fwd (gelu)", 290000, 768, 192, "gelu", BF16),
     ("dec fc2 fwd", 290000, 192, 768, "none", BF16),
+    ("dec fc1 fwd (gelu_grad)", 290000, 768, 192, "gelu_grad", BF16),
+    ("dec fc2 dgrad (mul)", 290000, 768, 192, "mul", BF16),
+    ("dec fc1 dgrad", 290000, 192, 768, "none", BF16),
+    ("dec proj fwd", 290000, 192, 192, "none", BF16),
+    ("dec qkv dgrad", 290000, 192, 576, "none", BF16),
+    ("dec embed", 72000, 192, 384, "none", BF16),
     ("patch embed", 72000, 384, 192, "none", F32),
     ("pred head", 218000, 192, 192, "none", F32),
     # cache-resident probes (operands + output fit the 256 MiB Infinity Cache after the first round)
@@ -35,6 +41,14 @@ SHAPES = [  # name, M, N, K, epilogue, out dtype
     ("probe fc2 M=32768", 32768, 384, 1536, "none", BF16),
     ("probe fc1 none", 72000, 1536, 384, "none", BF16),
     ("probe K=4096", 32768, 1152, 4096, "none", BF16),
+    # ViT-B/16 (batch 512: 25088 encoder rows, 100864 decoder rows at width 512) and ViT-L/14 (65536 rows) shapes
+    ("vitb qkv fwd", 25088, 2304, 768, "none", BF16),
+    ("vitb fc1 fwd (gelu_grad)", 25088, 3072, 768, "gelu_grad", BF16),
+    ("vitb fc2 fwd", 25088, 768, 3072, "none", BF16),
+    ("vitb dec fc1 (gelu_grad)", 100864, 2048, 512, "gelu_grad", BF16),
+    ("vitb dec fc2 fwd", 100864, 512, 2048, "none", BF16),
+    ("vitl fc1 fwd (gelu_grad)", 65536, 4096, 1024, "gelu_grad", BF16),
+    ("vitl fc2 fwd", 65536, 1024, 4096, "none", BF16),
 ]
 WGRAD_SHAPES = [  # name, M, N, K   (dW[N,K] = dY[M,N]^T A[M,K], db = colsum dY)
     ("enc qkv wgrad", 72000, 1152, 384), ("enc proj wgrad", 72000, 384, 384), ("enc fc1 wgrad", 72000, 1536, 384),
