@@ -65,7 +65,23 @@ __device__ __forceinline__ void unpack8(const bf16x8& v, f32x4& a, f32x4& b) {
 }
 __device__ __forceinline__ void ld8(const float* p, f32x4& a, f32x4& b) { a = load4(p); b = load4(p + 4); }
 __device__ __forceinline__ void ld8(const bf16* p, f32x4& a, f32x4& b) { unpack8(*reinterpret_cast<const bf16x8*>(p), a, b); }
-template <class V> __device__ __forceinline__ void stream_store(V v, V* p) { __builtin_nontemporal_store(v, p); }
+// Outputs are written once and read by a LATER kernel: non-temporal stores (see gemm_nt2_kernel).  -DMAE_NT3_STORE=1 / 2 / 3 build
+// the plain / sc1 / sc0 sc1 forms for A/B runs of the whole step (profiles/r03_nt3_kloop.txt).
+#ifndef MAE_NT3_STORE
+#define MAE_NT3_STORE 0
+#endif
+template <class V> __device__ __forceinline__ void stream_store(V v, V* p) {
+  static_assert(sizeof(V) == 16, "16-byte stores only");
+#if MAE_NT3_STORE == 0
+  __builtin_nontemporal_store(v, p);
+#elif MAE_NT3_STORE == 1
+  *p = v;
+#elif MAE_NT3_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
 __device__ __forceinline__ void st8(float* p, const f32x4& a, const f32x4& b) {
   stream_store(a, reinterpret_cast<f32x4*>(p));
   stream_store(b, reinterpret_cast<f32x4*>(p + 4));
@@ -88,6 +104,10 @@ __device__ __forceinline__ bf16x8 row_swap8(const bf16x8& v) {
 // the descriptor's num_records (out of range -> zeros, no fault).
 __device__ __forceinline__ void dma16(const i32x4& rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// the same with the non-temporal cache policy (streamed-once rows: the lines are not kept in L2)
+__device__ __forceinline__ void dma16_nt(const i32x4& rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void dma4(const i32x4& rsrc, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -133,7 +153,7 @@ struct Spread {
 template <int MODE, class TO, bool HAS_BIAS, int NI, int MI, int WM>
 __global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M, int N, int K,
                                                                const float* __restrict__ bias, const void* __restrict__ aux, TO* __restrict__ out,
-                                                               TO* __restrict__ out2, int tiles_m, int tiles_n) {
+                                                               TO* __restrict__ out2, int tiles_m, int tiles_n, int a_nt) {
   using G_ = Geo3<NI, MI, WM>;
   using SP = Spread<MI, NI, G_::GPW>;
   constexpr int BM = G_::BM, BN = G_::BN, ASTG = G_::ASTG, WSTG = G_::WSTG, SA = G_::SA, SW = G_::SW, NA = G_::NA, NW = G_::NW, GPW = G_::GPW;
@@ -178,7 +198,8 @@ __global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __res
   const uint32_t piece = 8u * rowbytes;
   auto issue_a = [&](int q) {
 #ifndef MAE_DBG_NO_DMA
-    dma16(rsA, sa.lds + (uint32_t)(q * 1024), voff, sa.base + (uint32_t)q * piece);
+    if (a_nt) dma16_nt(rsA, sa.lds + (uint32_t)(q * 1024), voff, sa.base + (uint32_t)q * piece);
+    else dma16(rsA, sa.lds + (uint32_t)(q * 1024), voff, sa.base + (uint32_t)q * piece);
 #endif
   };
   auto issue_w = [&](int q) {
@@ -398,6 +419,9 @@ __global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __res
     mfma_range<NR, MI * NI>(acc, af0, bf0);                                                                        \
     __builtin_amdgcn_sched_barrier(0);
 
+#ifdef MAE_DBG_NT3_CLOCK   // alternate build: the in-kernel clock and cycles per K-step of one wave (printf perturbs the launch a little)
+  const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int tile = 0; tile < ntile; ++tile) {
     // ---- a tile's first step: the previous tile is completed by phase 1 and stored before phase 2
     // (outstanding at the wait: the activation pieces issued after the awaited weight pieces in the previous step)
@@ -425,6 +449,13 @@ __global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __res
     const int p_tm = c_tm - dq - (c_tn - dr < 0 ? 1 : 0), p_tn = c_tn - dr < 0 ? c_tn - dr + tiles_n : c_tn - dr;
     epilogue((int64_t)p_tm * BM, p_tn * BN, (ntile - 1) & 1);
   }
+#ifdef MAE_DBG_NT3_CLOCK
+  if (blockIdx.x == 100 && tid == 0) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    printf("nt3 clock: M %d N %d K %d mode %d tile %dx%d | %d tiles x %d steps | %.2f GHz | %d cycles per step | %.1f us\n", (int)M, N, K, MODE, BM, BN, ntile, nk,
+           (double)(t1 - ck_t0) / (double)(r1 - ck_r0) * 0.1, (int)((t1 - ck_t0) / (unsigned long long)(ntile * nk)), (double)(r1 - ck_r0) * 0.01);
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the phantom pieces issued past the last tile land before the LDS is released
 #undef NT3_PHASE2
 #undef NT3_PHASE1
@@ -440,14 +471,17 @@ static int launch_nt3(const bf16* A, const bf16* W, int64_t M, int N, int K, con
   MAE_REQUIRE(T < (1ll << 30), "gemm: too many tiles");
   const int tiles_m = (int)cdiv(M, G_::BM), tiles_n = N / G_::BN;
   const int grid = (int)std::min<int64_t>(T, (int64_t)num_cus() * (WM == 4 ? 1 : 2));  // persistent: one 8-wave or two 4-wave workgroups per CU
+  // activation rows that few workgroups share are streamed with the non-temporal policy (MAE_NT3_ANT = largest tiles_n that gets it; A/B)
+  static const int ant_max = [] { const char* v = getenv("MAE_NT3_ANT"); return v ? atoi(v) : 0; }();
+  const int a_nt = tiles_n <= ant_max ? 1 : 0;
   if (e.bias) {
     auto kern = gemm_nt3_kernel<MODE, TO, true, NI, MI, WM>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n, a_nt);
   } else {
     auto kern = gemm_nt3_kernel<MODE, TO, false, NI, MI, WM>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n, a_nt);
   }
   MAE_LAUNCH_CHECK();
   return 0;

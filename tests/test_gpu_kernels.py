@@ -300,6 +300,42 @@ def test_attention_fwd_bwd(dev, B, T, H, hd, dt):
     assert rel_err(dqkv.float(), qr.grad) < (5e-5 if dt == F32 else 2e-2)
 
 
+# ---------------------------------------------------------------------------------- NT GEMM: round 3's K-loop against round 2's
+@pytest.mark.parametrize("shape", [(70000, 1536, 384), (4099, 384, 192), (33000, 1152, 384), (9000, 384, 1536), (20000, 512, 256), (300, 192, 192),
+                                   (9000, 512, 1024), (72000, 384, 384), (1, 192, 192), (257, 576, 192)])
+def test_nt3_kernel_is_bit_identical_to_nt2(dev, shape):
+    """gemm_nt3_kernel (split LDS rings, pipelined K-step, scalar-offset buffer DMA, phantom pieces past the last tile) keeps
+    round 2's tiles, fragment layout, K order and epilogue arithmetic: every output bit must equal gemm_nt2_kernel's
+    (MAE_GEMM_NT=v2 pins the old kernel), for each epilogue the engine's bf16 path uses, both output types, full and ragged
+    tiles, one and many tiles per workgroup, nk = 3 .. 24."""
+    import os
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(5)
+    A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    W = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.rand(N, device=dev, generator=g)
+    MODE = {"none": 0, "gelu_grad": 4, "mul": 5, "gelu_act": 6}
+    try:
+        for epi, odt, with_bias in [("none", BF16, True), ("none", BF16, False), ("none", F32, True), ("gelu_grad", BF16, True), ("mul", BF16, False), ("gelu_act", BF16, True)]:
+            aux = (torch.rand(M, N, device=dev, generator=g) * 4 - 2).to(torch.bfloat16) if epi == "mul" else None
+            outs = {}
+            for var in ("v2", "v3"):
+                os.environ["MAE_GEMM_NT"] = var
+                o = torch.full((M, N), float("nan"), dtype=TDT[odt], device=dev)
+                o2 = torch.full((M, N), float("nan"), dtype=TDT[odt], device=dev)
+                for _rep in range(2):
+                    check(lib.mae_linear_fwd(_ptr(A), _ptr(W), _ptr(bias) if with_bias else None, M, N, K, BF16, MODE[epi], odt, _ptr(o),
+                                             _ptr(o2) if epi == "gelu_grad" else None, _ptr(aux) if aux is not None else None, stream(dev)))
+                torch.cuda.synchronize()
+                outs[var] = (o, o2)
+            assert torch.isfinite(outs["v3"][0]).all(), (epi, odt)
+            assert torch.equal(outs["v2"][0], outs["v3"][0]), (epi, odt, with_bias)
+            if epi == "gelu_grad":
+                assert torch.equal(outs["v2"][1], outs["v3"][1]), (epi, odt)
+    finally:
+        os.environ.pop("MAE_GEMM_NT", None)
+
+
 # ---------------------------------------------------------------------------------- hand-counted vmcnt waits
 def test_counted_vmcnt_waits_equal_the_all_drained_build(dev, tmp_path):
     """The persistent NT GEMM and the wgrad ring wait with hand-counted `s_waitcnt vmcnt(N)` (next stage's DMAs + the previous

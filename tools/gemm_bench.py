@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--variants", default="v2,v3")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--cold", action="store_true", help="evict the Infinity Cache before every timed launch (a 512 MiB fill), as inside a training step where the operand was written long before")
     ap.add_argument("--wgrad", action="store_true", help="time the weight-gradient GEMM (+ slab reduce) instead")
     ap.add_argument("--wgrad-pair", action="store_true", help="time the paired weight-gradient launch against the two launches it replaces")
     ap.add_argument("--wgrad-variants", default="v2", help="comma list of MAE_WGRAD values to A/B (v1 | v2 | v2r | v3 | v3r)")
@@ -149,6 +150,7 @@ def main():
         return wgrad_main(args, dev)
     variants = args.variants.split(",")
     g = torch.Generator(device=dev).manual_seed(1)
+    flush = torch.zeros(128 << 20, dtype=torch.int32, device=dev) if args.cold else None
     for name, M, N, K, epi, odt in SHAPES:
         if args.only and not any(o in name for o in args.only.split(',')):
             continue
@@ -174,6 +176,8 @@ def main():
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for v in variants:
+                if args.cold:
+                    flush.add_(1); torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(); run(v); e1.record(); torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) * 1e3)
