@@ -10,8 +10,9 @@ mask_ratio 0.75, bf16 MFMA operands / fp32 accumulate, batch 2000 per GPU (BASEL
 One JSON line on rank 0.  `value` is whole-job images/s with inputs resident in HBM (K steps, barrier + synchronize on
 both sides, max over ranks).  `roofline` prices the dominant kernel class (the bf16 MFMA Linear GEMM, forward + dgrad
 launches) from HIP events recorded on the launch stream around every launch, in a second pass over the same K steps
-(the ~860 events per step cost ~5 % and would otherwise distort `value`); `traffic` is the HBM bytes per launch of that
-kernel from the committed rocprofv3 PMC passes.  `cpu_baseline` times the CPU oracle (the torch fp32 restatement of the
+(the ~860 events per step cost ~5 % and would otherwise distort `value`): `bound` is the roof the class's flop per
+algorithmic byte falls under (hbm below the 312 flop/B ridge), `frac` the fraction of that roof, `frac_mfma` and
+`frac_hbm` both; `traffic` is the HBM bytes per launch of that kernel from the newest committed rocprofv3 PMC passes.  `cpu_baseline` times the CPU oracle (the torch fp32 restatement of the
 reference path) on the host cores, rank 0 / N=1 only, on a bounded sample (ViT-S/8, batch 64).
 """
 from __future__ import annotations
@@ -64,12 +65,20 @@ def jepa_flops_per_image_step(general, encoder, predictor, k: float, m: int) -> 
     return 3.0 * (enc(k) + pred) + enc(N)
 
 
-PMC_FILE = ROOT / "profiles" / "r02_pmc_hbm_traffic_per_launch.json"
+def _pmc_file():
+    """The newest committed PMC reduction of the default workload (profiles/rNN_pmc_hbm_traffic_per_launch.json)."""
+    files = sorted((ROOT / "profiles").glob("r[0-9][0-9]_pmc_hbm_traffic_per_launch.json"))
+    return files[-1] if files else None
+
+
+PMC_FILE = _pmc_file()
+NT_KERNEL = "gemm_nt3_kernel"   # the dominant kernel class: Linear forward + dgrad launches (k_gemm_nt3.hip)
 
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    tools/pmc_traffic.py); PMC counters cannot be read from inside the timed process, so this is the profiled value."""
+    tools/pmc_traffic.py); PMC counters cannot be read from inside the timed process, so this is the profiled value
+    (null until a profile of this kernel is committed)."""
     try:
         return json.loads(PMC_FILE.read_text())[kernel]["hbm_bytes_per_launch"]
     except Exception:
@@ -318,11 +327,24 @@ def main() -> None:
         }
         if kernels:
             k = kernels["linear_nt"]
-            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt2_kernel (Linear fwd + dgrad, persistent LDS-DMA ring, bf16 MFMA 16x16x32)",
-                               "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                               "traffic": pmc_traffic("gemm_nt2_kernel"), "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
+            sec = k["ms"] * 1e-3
+            tf = k["flops"] / sec / 1e12 if sec > 0 else 0.0          # algorithmic 2*M*N*K of the class / its HIP-event time
+            gbs = k["bytes"] / sec / 1e9 if sec > 0 else 0.0          # algorithmic operand + output + side-input bytes / the same time
+            frac_mfma, frac_hbm = tf / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
+            # the roof that binds is the one the class's arithmetic intensity falls under: flop per byte against the ridge
+            # peak_flops / peak_bytes (312 flop/B); `frac` is the fraction of THAT roof, both fractions are printed
+            intensity = k["flops"] / k["bytes"] if k["bytes"] > 0 else float("inf")
+            ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+            hbm_bound = intensity < ridge
+            out["roofline"] = {"bound": "hbm" if hbm_bound else "mfma",
+                               "kernel": NT_KERNEL + " (Linear fwd + dgrad, persistent LDS-DMA rings, bf16 MFMA 16x16x32)",
+                               "achieved": gbs if hbm_bound else tf, "peak": PEAK_HBM_GBS if hbm_bound else PEAK_BF16_TFLOPS,
+                               "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": frac_hbm if hbm_bound else frac_mfma,
+                               "frac_mfma": frac_mfma, "frac_hbm": frac_hbm, "achieved_tflops": tf, "achieved_gbs": gbs,
+                               "flop_per_byte": intensity, "ridge_flop_per_byte": ridge,
+                               "traffic": pmc_traffic(NT_KERNEL), "avg_launch_us": 1e3 * k["ms"] / max(1, k["launches"]),
                                "launches": k["launches"], "algorithmic_bytes_per_launch": k["bytes"] / max(1, k["launches"]),
+                               "algorithmic_flops_per_launch": k["flops"] / max(1, k["launches"]),
                                "measured_in": "second pass over the same K steps with per-launch HIP events on the launch stream",
                                "ms_per_step_with_events": timed_ms}
             tot_ms = sum(v["ms"] for v in kernels.values())
