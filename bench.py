@@ -250,18 +250,19 @@ def main() -> None:
     model = module.model
     L = (img // int(general["patch_size"])) ** 2 + 1
 
-    # synthetic inputs, resident in HBM before the timed region; every rank draws the global tensors and keeps its rows
-    g = torch.Generator(device=dev).manual_seed(73)
-    images = (torch.rand(B * world, chans, img, img, device=dev, generator=g) * 2 - 1)[rank * B:(rank + 1) * B].contiguous()
+    # synthetic inputs, resident in HBM before the timed region; every rank draws ITS rows only (a generator seeded per rank: weak
+    # scaling has no global tensor to agree on, and 8 ranks drawing 16 000 images each would cost 8 x the memory and the time)
+    g = torch.Generator(device=dev).manual_seed(73 + 1009 * rank)
+    images = torch.rand(B, chans, img, img, device=dev, generator=g) * 2 - 1
     total = args.warmup + args.steps
     if predictor:  # per-step multi-block masks of the GLOBAL batch (host sampler, seeded), this rank's rows, uploaded before timing
-        mg = torch.Generator().manual_seed(73)
-        masks = [model.sample_masks(B * world, mg) for _ in range(total)]
-        noises = [(c[rank * B:(rank + 1) * B].to(dev), t[rank * B:(rank + 1) * B].to(dev)) for c, t in masks]
+        mg = torch.Generator().manual_seed(73)   # the SAME block sizes on every rank (context length is a per-step scalar), own positions
+        masks = [model.sample_masks(B, mg) for _ in range(total)]
+        noises = [(c.to(dev), t.to(dev)) for c, t in masks]
         model.reserve_workspace(B, max(c.shape[1] for c, _t in masks), masks[0][1].shape[1], max(t.shape[2] for _c, t in masks))  # no reallocation inside the timed region
         step_fn = lambda i: module.fused_training_step(images, noises[i][0], noises[i][1])  # noqa: E731
     else:
-        noises = [torch.rand(B * world, L, device=dev, generator=g)[rank * B:(rank + 1) * B].contiguous() for _ in range(total)]
+        noises = [torch.rand(B, L, device=dev, generator=g) for _ in range(total)]
         step_fn = lambda i: module.fused_training_step(images, noises[i])  # noqa: E731
 
     def sync():

@@ -47,16 +47,16 @@ def main(argv=None):
         with open(output_dir / "config.yaml", "w") as f_out:
             yaml.safe_dump(cfg, f_out)
 
-    global_batch = int(pre_cfg["batch_size"])
-    if global_batch % world:
-        raise SystemExit(f"batch_size {global_batch} must be divisible by the number of GPUs {world}")
     data_cfg = dict(cfg, pretrain=dict({"val_split": 0.06, "data_fraction": 1.0}, **pre_cfg))
-    train_batches, val_batches = get_pretrain_batches(data_cfg, dev, synthetic_images=args.synthetic_images, seed=SEED)
+    train_batches, val_batches = get_pretrain_batches(data_cfg, dev, synthetic_images=args.synthetic_images, seed=SEED, rank=rank, world=world)
 
     module = IJEPAPretrainModule(model_cfg=model_cfg, training_cfg=pre_cfg).to(dev)
     start_epoch, resumed = load_checkpoint(args.resume_from, module) if args.resume_from else (0, {})
     module = module.to(dev)
     model = module.model
+    # the EMA momentum schedule runs over the optimizer steps this loop really takes (every global batch of an epoch, ragged last one
+    # included, capped by --max_steps_per_epoch), not over the config's fallback count
+    module.steps_per_epoch = train_batches.steps_per_epoch if args.max_steps_per_epoch is None else min(train_batches.steps_per_epoch, args.max_steps_per_epoch)
     best_val = float(resumed.get("best_val_loss", float("inf")))
     log_path = output_dir / "logs" / "metrics.jsonl"
     val_gen = torch.Generator().manual_seed(SEED + 1)
@@ -65,20 +65,17 @@ def main(argv=None):
         module.current_epoch = epoch
         module.on_train_epoch_start()
         t0, seen, steps, loss_sum = time.perf_counter(), 0, 0, torch.zeros(1, device=dev)
-        for step, images in enumerate(train_batches(epoch)):
+        for step, sb in enumerate(train_batches(epoch)):
             if args.max_steps_per_epoch is not None and step >= args.max_steps_per_epoch:
                 break
-            gb = images.shape[0]
-            if gb % world:
-                continue
-            ctx, tgt = model.sample_masks(gb, module.mask_generator)  # masks of the GLOBAL batch (every rank draws the same), own rows kept
-            loss = module.fused_training_step(mdist.shard_rows(images, rank, world), mdist.shard_rows(ctx, rank, world), mdist.shard_rows(tgt, rank, world))
+            ctx, tgt = model.sample_masks(sb.global_rows, module.mask_generator)  # masks of the GLOBAL batch (every rank draws the same), own rows kept
+            loss = module.fused_training_step(sb.images, ctx[sb.lo:sb.hi].contiguous(), tgt[sb.lo:sb.hi].contiguous(), global_rows=sb.global_rows)
             loss_sum += loss
-            seen += gb
+            seen += sb.global_rows
             steps += 1
         val = torch.zeros(2, device=dev, dtype=torch.float64)
-        for images in val_batches():
-            imgs = images[rank::world].contiguous()
+        for sb in val_batches():
+            imgs = sb.images
             if imgs.shape[0] == 0:
                 continue
             ctx, tgt = model.sample_masks(imgs.shape[0], val_gen)

@@ -82,10 +82,7 @@ def main(argv=None):
     start_epoch, resumed = load_checkpoint(args.resume_from, module) if args.resume_from else (0, {})
     module = module.to(dev)
     L = module.model.sequence_length
-    global_batch = int(pre_cfg["batch_size"])
-    if global_batch % world:
-        raise SystemExit(f"batch_size {global_batch} must be divisible by the number of GPUs {world}")
-    train_batches, val_batches = get_pretrain_batches(cfg, dev, synthetic_images=args.synthetic_images, seed=SEED)
+    train_batches, val_batches = get_pretrain_batches(cfg, dev, synthetic_images=args.synthetic_images, seed=SEED, rank=rank, world=world)
 
     # resume bookkeeping: best validation loss so far (kept in last.ckpt, else read from the best.ckpt next to it)
     best_val, log_path = float("inf"), output_dir / "logs" / "metrics.jsonl"
@@ -99,22 +96,21 @@ def main(argv=None):
         module.current_epoch = epoch
         module.on_train_epoch_start()
         t0, seen, steps, loss_sum = time.perf_counter(), 0, 0, torch.zeros(1, device=dev)
-        for step, images in enumerate(train_batches(epoch)):
+        for step, sb in enumerate(train_batches(epoch)):
             if args.max_steps_per_epoch is not None and step >= args.max_steps_per_epoch:
                 break
-            gb = images.shape[0]
-            if gb % world:
-                continue  # ragged tail of the epoch cannot be sharded evenly; the reference (1 GPU) has no such case
-            noise = mdist.global_noise(gb, L, SEED, module.global_step, dev)
-            loss = module.fused_training_step(mdist.shard_rows(images, rank, world), mdist.shard_rows(noise, rank, world))
+            # this rank's rows of the global batch (fetched for these rows only) and of the global noise (drawn whole: 145 floats per
+            # image, so that W-GPU masks equal the one-GPU run); a ragged last batch is weighted by the rows each rank holds
+            noise = mdist.global_noise(sb.global_rows, L, SEED, module.global_step, dev)[sb.lo:sb.hi].contiguous()
+            loss = module.fused_training_step(sb.images, noise, global_rows=sb.global_rows)
             loss_sum += loss  # already the global mean (it rides through the gradient all-reduce)
-            seen += gb
+            seen += sb.global_rows
             steps += 1
-        # validation (masked-reconstruction MSE, no grad): rank r takes rows r::world of every batch, the sums are reduced
+        # validation (masked-reconstruction MSE, no grad): every rank scores its rows of every batch, the sums are reduced
         val = torch.zeros(2, device=dev, dtype=torch.float64)  # [sum of per-image losses, images]
         with torch.no_grad():
-            for images in val_batches():
-                imgs = images[rank::world].contiguous()
+            for sb in val_batches():
+                imgs = sb.images
                 if imgs.shape[0] == 0:
                     continue
                 preds, targets = module.model(imgs)

@@ -95,6 +95,11 @@ int launch_gather_patches_u8(const uint8_t* images, const int32_t* tok, int B, i
   MAE_REQUIRE(C * p * img <= 96 * 1024 && k <= 8192, "uint8 images: one row of patches (%d bytes) does not fit the LDS band", C * p * img);
   const int grid = (int)std::min<int64_t>((int64_t)B * (img / p), 256 * 16);
   const size_t lds = (size_t)C * p * img + (size_t)k * 4;
+  // band + token list may exceed the 64 KiB a kernel gets by default (up to 96 + 32 KiB are admitted above)
+  if (lds > 64 * 1024) {
+    MAE_HIP(hipFuncSetAttribute((const void*)gather_patches_u8_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MAE_HIP(hipFuncSetAttribute((const void*)gather_patches_u8_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   if (dt == MAE_BF16) hipLaunchKernelGGL((gather_patches_u8_kernel<bf16>), dim3(grid), dim3(256), lds, s, images, tok, B, k, C, img, p, (bf16*)out);
   else hipLaunchKernelGGL((gather_patches_u8_kernel<float>), dim3(grid), dim3(256), lds, s, images, tok, B, k, C, img, p, (float*)out);
   MAE_LAUNCH_CHECK();
@@ -164,6 +169,11 @@ int launch_mse_from_images_u8(const float* pred, const uint8_t* images, const in
   const int grid = (int)std::min<int64_t>((int64_t)B * (img / p), 1024);  // stage-1 partials: scratch holds 1024 floats + 8
   const float gs = grad_scale * 2.0f / (float)n;
   const size_t lds = (size_t)C * p * img + (size_t)m * 4;
+  if (lds > 64 * 1024) {
+    MAE_HIP(hipFuncSetAttribute((const void*)mse_images_u8_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MAE_HIP(hipFuncSetAttribute((const void*)mse_images_u8_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MAE_HIP(hipFuncSetAttribute((const void*)mse_images_u8_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
   if (!d_pred)
     hipLaunchKernelGGL((mse_images_u8_kernel<float, false>), dim3(grid), dim3(256), lds, s, pred, images, mask32, B, m, C, img, p, gs, scratch, (float*)nullptr);
   else if (dpred_dt == MAE_BF16)
@@ -230,7 +240,9 @@ static int launch_patchify_u8(const uint8_t* images, const I* mask, int B, int m
   MAE_REQUIRE(p > 0 && img % p == 0 && p % 4 == 0 && img / p <= 64 && C * p * img <= 96 * 1024, "uint8 images: unsupported geometry (image %d, patch %d)", img, p);
   MAE_REQUIRE(m <= 8192, "patchify_gather(u8): too many tokens per image");
   const int grid = (int)std::min<int64_t>((int64_t)B * (img / p), 256 * 16);
-  hipLaunchKernelGGL((patchify_gather_u8_kernel<I>), dim3(grid), dim3(256), (size_t)C * p * img + (size_t)m * 4, s, images, mask, B, m, C, img, p, target);
+  const size_t lds = (size_t)C * p * img + (size_t)m * 4;
+  if (lds > 64 * 1024) MAE_HIP(hipFuncSetAttribute((const void*)patchify_gather_u8_kernel<I>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((patchify_gather_u8_kernel<I>), dim3(grid), dim3(256), lds, s, images, mask, B, m, C, img, p, target);
   MAE_LAUNCH_CHECK();
   return 0;
 }

@@ -67,12 +67,16 @@ def random_resized_crop_params(n: int, size: int, gen: torch.Generator, scale=(0
     return top, left, h, w
 
 
-def augment_batch(x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
-    """RandomResizedCrop(size, scale=(0.8, 1.0)) + RandomHorizontalFlip() on a (B, C, S, S) float batch, on its device."""
+def augment_batch(x: torch.Tensor, gen: Optional[torch.Generator] = None, params=None) -> torch.Tensor:
+    """RandomResizedCrop(size, scale=(0.8, 1.0)) + RandomHorizontalFlip() on a (B, C, S, S) float batch, on its device
+    (``params``: the output of ``draw_augment_params`` sliced to the batch's rows, instead of drawing them here)."""
     import torch.nn.functional as F
     B, _, S, _ = x.shape
-    top, left, h, w = random_resized_crop_params(B, S, gen)
-    flip = torch.rand(B, generator=gen, device=gen.device) < 0.5
+    if params is None:
+        top, left, h, w = random_resized_crop_params(B, S, gen)
+        flip = torch.rand(B, generator=gen, device=gen.device) < 0.5
+    else:
+        top, left, h, w, flip = params
     # affine grid in normalised coordinates (align_corners=False): output pixel centres map to the crop box
     sx = w.to(torch.float32) / S; sy = h.to(torch.float32) / S
     cx = (2.0 * left.to(torch.float32) + w.to(torch.float32)) / S - 1.0
@@ -85,17 +89,26 @@ def augment_batch(x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
     return F.grid_sample(x, grid, mode="bilinear", padding_mode="border", align_corners=False)
 
 
-def augment_batch_u8(x: torch.Tensor, gen: torch.Generator) -> torch.Tensor:
+def draw_augment_params(n: int, size: int, gen: torch.Generator):
+    """Crop boxes and flips of n images: (top, left, h, w, flip) integer tensors on the generator's device.  Drawn for the
+    GLOBAL batch on every rank (five numbers per image) and sliced to the rank's rows, so that a data-parallel run augments
+    every image exactly as the one-GPU run does."""
+    top, left, h, w = random_resized_crop_params(n, size, gen)
+    flip = torch.rand(n, generator=gen, device=gen.device) < 0.5
+    return top, left, h, w, flip
+
+
+def augment_batch_u8(x: torch.Tensor, gen: Optional[torch.Generator] = None, params=None) -> torch.Tensor:
     """The same augmentation on a uint8 device batch, by the HIP kernel behind ``mae_augment_crop_flip_u8`` (uint8 in, uint8
     out, as the reference's PIL transforms run before ToTensor): the crop boxes and flips are drawn here with the rule of
-    ``random_resized_crop_params``, the resampling runs in libmae_hip.so.  No torch fallback: a missing extension fails loudly."""
+    ``random_resized_crop_params`` (or passed in as ``params``, already sliced to the batch's rows), the resampling runs in
+    libmae_hip.so.  No torch fallback: a missing extension fails loudly."""
     from ._lib import check, lib, ptr
     from .mae import _stream
     if x.dtype != torch.uint8 or not x.is_cuda or x.dim() != 4 or x.shape[2] != x.shape[3]:
         raise ValueError(f"augment_batch_u8 needs a square (B, C, S, S) uint8 CUDA batch, got {tuple(x.shape)} {x.dtype} on {x.device}")
     B, C, S, _ = x.shape
-    top, left, h, w = random_resized_crop_params(B, S, gen)
-    flip = torch.rand(B, generator=gen, device=gen.device) < 0.5
+    top, left, h, w, flip = draw_augment_params(B, S, gen) if params is None else params
     params = torch.stack([top, left, h, w, flip.to(torch.int64)], dim=1).to(device=x.device, dtype=torch.int32).contiguous()
     x = x.contiguous()
     out = torch.empty_like(x)
@@ -141,7 +154,12 @@ class PinnedBatchStream:
 
     def batches(self, order: torch.Tensor) -> Iterator[torch.Tensor]:
         order = order.to("cpu", torch.int64)
-        chunks = [order[i:i + self.batch] for i in range(0, order.numel(), self.batch)]
+        return self.batches_of([order[i:i + self.batch] for i in range(0, order.numel(), self.batch)])
+
+    def batches_of(self, chunks) -> Iterator[torch.Tensor]:
+        """The same pipeline over explicit index chunks (each at most ``batch`` long; a chunk may be empty: a data-parallel rank's
+        share of a short last batch)."""
+        chunks = [c.to("cpu", torch.int64) for c in chunks]
         if not chunks:
             return
         n_next = self._submit(0, chunks[0])
@@ -155,14 +173,32 @@ class PinnedBatchStream:
             self.free[slot].record(torch.cuda.current_stream(self.device))  # everything the consumer enqueued on it so far
 
 
-def get_pretrain_batches(cfg: dict, device: torch.device, synthetic_images: Optional[int] = None,
-                         seed: int = 73) -> Tuple[Callable[[int], Iterator[torch.Tensor]], Callable[[], Iterator[torch.Tensor]]]:
+class ShardedBatch:
+    """What the training loops get per step under data parallelism: THIS rank's rows of a global batch (fetched / copied /
+    augmented for these rows only), the global row count and the rank's row range inside it."""
+    __slots__ = ("images", "global_rows", "lo", "hi")
+
+    def __init__(self, images: torch.Tensor, global_rows: int, lo: int, hi: int):
+        self.images, self.global_rows, self.lo, self.hi = images, int(global_rows), int(lo), int(hi)
+
+
+def get_pretrain_batches(cfg: dict, device: torch.device, synthetic_images: Optional[int] = None, seed: int = 73, rank: int = 0,
+                         world: int = 1) -> Tuple[Callable[[int], Iterator["ShardedBatch"]], Callable[[], Iterator["ShardedBatch"]]]:
+    """(train_batches(epoch), val_batches()): iterators of ``ShardedBatch``.  The order of the global batches and their
+    augmentation parameters do not depend on the world size; rank r fetches rows [gb r / W, gb (r + 1) / W) of each global
+    batch only (the last batch of an epoch may be ragged: no batch is dropped, as in the reference, src/data.py:86-92).
+    ``train_batches.steps_per_epoch`` = global batches per epoch."""
     pre = cfg["pretrain"]
     batch = int(pre.get("batch_size", 512))
     val_split = float(pre.get("val_split", 0.1))
     fraction = float(pre.get("data_fraction", 1.0))
     seed = int(cfg.get("seed", seed))
     on_device = bool(cfg.get("engine", {}).get("data_on_device", True))
+    patch = int(cfg.get("model", {}).get("general", {}).get("patch_size", 8))
+    img_size = int(cfg.get("model", {}).get("general", {}).get("image_size", 96))
+    # the uint8 pixel kernels take patch sizes that are multiples of 4 (csrc/k_pixels_u8.hip); other geometries (the reference
+    # class's default patch_size 6, ViT-L/14) are served normalised fp32 batches, which every engine kernel accepts
+    keep_u8 = patch % 4 == 0 and img_size // max(1, patch) <= 64
     stream: Optional[PinnedBatchStream] = None
     if synthetic_images is None and STL10_UNLABELED.exists():
         host = _load_stl10_unlabeled(STL10_UNLABELED, fraction)
@@ -171,7 +207,7 @@ def get_pretrain_batches(cfg: dict, device: torch.device, synthetic_images: Opti
             data = host.to(device)  # uint8 on device; the engine normalises while it reads
             fetch = lambda idx: data[idx]  # noqa: E731
         else:
-            stream = PinnedBatchStream(host.pin_memory(), batch, device)
+            stream = PinnedBatchStream(host.pin_memory(), (batch + world - 1) // world + 1, device)
             fetch = None
     else:
         n_total = int(synthetic_images or 4 * batch)
@@ -183,32 +219,48 @@ def get_pretrain_batches(cfg: dict, device: torch.device, synthetic_images: Opti
     perm = torch.randperm(n_total, generator=torch.Generator().manual_seed(seed))  # random_split's permutation
     idx_dev = torch.device("cpu") if stream is not None else device
     train_idx, val_idx = perm[:n_train].to(idx_dev), perm[n_train:].to(idx_dev)
-    print(f"Unlabeled pretrain split: {n_train} train, {n_val} val ({val_split * 100:.1f}% validation)")
+    if rank == 0:
+        print(f"Unlabeled pretrain split: {n_train} train, {n_val} val ({val_split * 100:.1f}% validation)")
 
     augment = fraction < 1.0  # the reference's quirk: see the module docstring
     aug_gen = torch.Generator(device=device).manual_seed(seed + 7)
 
-    def finish(x: torch.Tensor) -> torch.Tensor:
-        if not augment:
-            return x.contiguous()  # uint8 stays uint8: normalised inside the engine
-        if x.dtype == torch.uint8 and x.is_cuda:
-            return augment_batch_u8(x, aug_gen)  # HIP resampler: uint8 in, uint8 out, normalised inside the engine
-        x = normalize_u8(x) if x.dtype == torch.uint8 else x  # synthetic float batches / host tensors: torch resampling
-        return augment_batch(x, aug_gen).contiguous()
+    def finish(x: torch.Tensor, lo: int, hi: int, gb: int) -> torch.Tensor:
+        params = None
+        if hi == lo:   # this rank holds no row of a short last batch (the generator still advances below, in step with the other ranks)
+            if augment:
+                draw_augment_params(gb, x.shape[-1], aug_gen)
+            return (x if (x.dtype == torch.uint8 and keep_u8) else normalize_u8(x) if x.dtype == torch.uint8 else x).contiguous()
+        if augment:  # parameters of the whole global batch (cheap), this rank's rows of them
+            params = tuple(t[lo:hi] for t in draw_augment_params(gb, x.shape[-1], aug_gen))
+        if x.dtype == torch.uint8 and x.is_cuda and keep_u8:
+            return augment_batch_u8(x, params=params) if augment else x.contiguous()  # uint8 stays uint8: normalised inside the engine
+        x = normalize_u8(x) if x.dtype == torch.uint8 else x
+        return (augment_batch(x, params=params) if augment else x).contiguous()
 
-    def serve(order: torch.Tensor) -> Iterator[torch.Tensor]:
+    def shards(order: torch.Tensor):
+        from .dist import shard_bounds
+        for i in range(0, order.numel(), batch):  # no drop_last, like the reference
+            idx = order[i:i + batch]
+            lo, hi = shard_bounds(idx.numel(), rank, world)
+            yield idx[lo:hi], idx.numel(), lo, hi
+
+    def serve(order: torch.Tensor) -> Iterator[ShardedBatch]:
         if stream is not None:
-            for x in stream.batches(order):
-                yield finish(x)
+            plan = list(shards(order))
+            for (idx, gb, lo, hi), x in zip(plan, stream.batches_of([p[0] for p in plan])):
+                yield ShardedBatch(finish(x, lo, hi, gb), gb, lo, hi)
         else:
-            for i in range(0, order.numel(), batch):  # no drop_last, like the reference
-                yield finish(fetch(order[i:i + batch]))
+            for idx, gb, lo, hi in shards(order):
+                yield ShardedBatch(finish(fetch(idx), lo, hi, gb), gb, lo, hi)
 
-    def train_batches(epoch: int) -> Iterator[torch.Tensor]:
+    def train_batches(epoch: int) -> Iterator[ShardedBatch]:
         g = torch.Generator().manual_seed(seed + 1000 + epoch)  # DataLoader(shuffle=True): a fresh order per epoch
         return serve(train_idx[torch.randperm(n_train, generator=g).to(train_idx.device)])
 
-    def val_batches() -> Iterator[torch.Tensor]:
+    def val_batches() -> Iterator[ShardedBatch]:
         return serve(val_idx)
 
+    train_batches.steps_per_epoch = (n_train + batch - 1) // batch
+    train_batches.n_train = n_train
     return train_batches, val_batches

@@ -31,13 +31,16 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     return rank, world
 
 
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of an n-row global batch that rank ``rank`` owns: contiguous, as even as possible (n need not divide by
+    the world size: the shares then differ by one row and the step weights each rank's mean by its share)."""
+    return n * rank // world, n * (rank + 1) // world
+
+
 def shard_rows(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
-    """Contiguous row shard of a global-batch tensor; the global batch must divide evenly (mean of means is then exact)."""
-    n = t.shape[0]
-    if n % world:
-        raise ValueError(f"global batch {n} is not divisible by world size {world}")
-    per = n // world
-    return t[rank * per:(rank + 1) * per].contiguous()
+    """Contiguous row shard of a global-batch tensor (see ``shard_bounds``)."""
+    lo, hi = shard_bounds(t.shape[0], rank, world)
+    return t[lo:hi].contiguous()
 
 
 def global_noise(global_batch: int, seq_len: int, seed: int, step: int, device: torch.device) -> torch.Tensor:

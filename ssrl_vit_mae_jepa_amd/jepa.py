@@ -275,8 +275,27 @@ class IJEPAPretrainModule(MAEPretrainModule):
         self.log("ema_momentum", self.ema_momentum())
 
     def ema_momentum(self) -> float:
+        """Linear ema_start -> ema_end over total_epochs * steps_per_epoch optimizer steps.  ``steps_per_epoch`` must be the
+        number of steps the training loop really runs per epoch: scripts/training/pretrain_ijepa.py sets it from its loader
+        (the config value, default 1000, is only a fallback: STL-10 unlabeled at batch 2000 has 47 steps per epoch, and a
+        schedule stretched over 1000 would end the run at 0.9962 instead of 1.0)."""
         total = max(1, self.total_epochs * self.steps_per_epoch)
         return self.ema_start + (self.ema_end - self.ema_start) * min(self.global_step, total) / total
+
+    def checkpoint_dict(self, epoch: int, weights_only: bool = False, extra=None):
+        """The MAE module's checkpoint plus the state of the host mask sampler (a uint8 tensor: the safe loader reads it), so
+        that a resumed run continues the mask sequence instead of replaying it from step 0."""
+        ckpt = super().checkpoint_dict(epoch, weights_only=weights_only, extra=extra)
+        ckpt["mask_generator_state"] = self.mask_generator.get_state().clone()
+        ckpt["steps_per_epoch"] = int(self.steps_per_epoch)
+        return ckpt
+
+    def load_checkpoint_dict(self, ckpt) -> int:
+        nxt = super().load_checkpoint_dict(ckpt)
+        st = ckpt.get("mask_generator_state")
+        if st is not None:
+            self.mask_generator.set_state(st.to(torch.uint8).cpu())
+        return nxt
 
     def forward(self, images: torch.Tensor):
         raise RuntimeError("IJEPAPretrainModule has no standalone forward: use fused_training_step(images) or model.loss_and_grads(...)")
@@ -298,13 +317,22 @@ class IJEPAPretrainModule(MAEPretrainModule):
         return stats
 
     def fused_training_step(self, images: torch.Tensor, idx_context: Optional[torch.Tensor] = None, idx_target: Optional[torch.Tensor] = None,
-                            lr: Optional[float] = None, momentum: Optional[float] = None, process_group=None) -> torch.Tensor:
+                            lr: Optional[float] = None, momentum: Optional[float] = None, process_group=None,
+                            global_rows: Optional[int] = None) -> torch.Tensor:
+        """``global_rows``: rows of the global batch this step belongs to (see MAEPretrainModule.fused_training_step): the rank's
+        mean loss and gradient are weighted by images.shape[0] / global_rows; a 0-row shard contributes zeros."""
         model = self.model
-        if idx_context is None or idx_target is None:
-            idx_context, idx_target = model.sample_masks(images.shape[0], self.mask_generator)
-        loss = self._exchanged_loss_and_grads(
-            lambda scale, events, out: model.loss_and_grads(images, idx_context, idx_target, grad_scale=scale, ready_events=events, loss_out=out),
-            process_group)
+        rows = int(images.shape[0])
+        weight = None if global_rows is None else rows / float(global_rows)
+        if rows == 0:
+            if global_rows is None:
+                raise ValueError("an empty shard needs global_rows")
+            compute = None
+        else:
+            if idx_context is None or idx_target is None:
+                idx_context, idx_target = model.sample_masks(rows, self.mask_generator)
+            compute = lambda scale, events, out: model.loss_and_grads(images, idx_context, idx_target, grad_scale=scale, ready_events=events, loss_out=out)  # noqa: E731
+        loss = self._exchanged_loss_and_grads(compute, process_group, weight)
         self.optimizer_step(lr, momentum)
         self.global_step += 1
         self.log("train_loss", loss)

@@ -110,8 +110,8 @@ class MAEPretrainModule(nn.Module):
         self.log("mask_ratio", new_mask, prog_bar=True)
 
     # ---- fused native step ------------------------------------------------------------------------
-    def current_lr(self) -> float:
-        return self.effective_lr * lr_lambda(self.current_epoch, self.warmup_epochs, self.total_epochs)
+    def current_lr(self, epoch: Optional[int] = None) -> float:
+        return self.effective_lr * lr_lambda(self.current_epoch if epoch is None else epoch, self.warmup_epochs, self.total_epochs)
 
     def _opt_state(self):
         dev = self.model.flat_params.device
@@ -167,16 +167,21 @@ class MAEPretrainModule(nn.Module):
             self._comm_stream = torch.cuda.Stream(device=dev)
         return self._bucket_events, self._comm_stream
 
-    def _exchanged_loss_and_grads(self, compute, process_group=None) -> torch.Tensor:
+    def _exchanged_loss_and_grads(self, compute, process_group=None, weight: Optional[float] = None) -> torch.Tensor:
         """Run ``compute(grad_scale, ready_events, loss_out)`` (a native loss+grads call) and, with torch.distributed
         initialised, sum the gradient buckets over the ranks as the backward pass finishes them.  Returns the GLOBAL mean
-        loss as a device scalar (no host sync); afterwards ``model.flat_grads`` holds the reduced gradients."""
+        loss as a device scalar (no host sync); afterwards ``model.flat_grads`` holds the reduced gradients.
+        ``weight`` = this rank's share of the global batch (local rows / global rows; default 1 / world, equal shards): the
+        local mean loss and its gradient are scaled by it before the sum, so a ragged last batch (the reference never drops
+        one, src/data.py:86-92) still yields the global mean.  ``compute`` is None on a rank that holds no row of the batch:
+        it contributes zeros to the same sequence of collectives."""
         model = self.model
         dev = model._require_cuda()
         dist = torch.distributed
         world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         if world == 1 and not (dist.is_available() and dist.is_initialized() and os.environ.get("MAE_DP_FORCE_EXCHANGE") == "1"):
             return compute(1.0, None, None)  # (MAE_DP_FORCE_EXCHANGE=1: rehearse the exchange on a one-rank RCCL group)
+        w = 1.0 / world if weight is None else float(weight)
         n = model.engine.trainable_elems
         buf = model.grad_buffer
         loss_slot = buf[n:n + 1]
@@ -184,32 +189,52 @@ class MAEPretrainModule(nn.Module):
             events, comm = self._exchange_state(dev)
             main = torch.cuda.current_stream(dev)
             comm.wait_stream(main)  # the previous step's optimizer has read the buffer before it is reduced into again
-            compute(1.0 / world, events, loss_slot)
+            if compute is None:
+                buf[:n + 1].zero_()
+                comm.wait_stream(main)
+            else:
+                compute(w, events, loss_slot)
             works = []
             with torch.cuda.stream(comm):
                 for j, b, e in self.gradient_buckets():
-                    comm.wait_event(events[j])
+                    if compute is not None:
+                        comm.wait_event(events[j])
+                    if compute is not None and b <= n < e:
+                        loss_slot.mul_(w)  # the loss was written before this bucket's event (it opens the backward pass): weight it ahead of the sum
                     works.append(dist.all_reduce(buf[b:e], op=dist.ReduceOp.SUM, group=process_group, async_op=True))
-                for w in works:
-                    w.wait()
+                for wk in works:
+                    wk.wait()
             main.wait_stream(comm)
         else:  # one blocking collective after the whole backward pass
-            compute(1.0 / world, None, loss_slot)
+            if compute is None:
+                buf[:n + 1].zero_()
+            else:
+                compute(w, None, loss_slot)
+                loss_slot.mul_(w)
             dist.all_reduce(buf[:n + 1], op=dist.ReduceOp.SUM, group=process_group)
-        return loss_slot / world  # sum of the ranks' local means / world = global mean (equal local batches)
+        return loss_slot * 1.0  # sum over ranks of (share x local mean) = the global mean; a copy: the slot is rewritten next step
 
     def fused_training_step(self, images: torch.Tensor, noise: Optional[torch.Tensor] = None, lr: Optional[float] = None,
-                            process_group=None) -> torch.Tensor:
+                            process_group=None, global_rows: Optional[int] = None) -> torch.Tensor:
         """One whole pretrain step.  With torch.distributed initialised every rank computes its rows of the global batch
-        with the loss gradient pre-divided by the world size, the gradient buckets are summed over RCCL as the backward
-        pass finishes them (on a side stream, behind the engine's gradient-ready events), and every rank then applies
-        the same global-norm clip + AdamW.  Returns the GLOBAL mean loss as a device scalar (no host sync)."""
+        with the loss gradient scaled by its share of the batch (``images.shape[0] / global_rows``; 1 / world when
+        ``global_rows`` is not given: equal shards), the gradient buckets are summed over RCCL as the backward pass finishes
+        them (on a side stream, behind the engine's gradient-ready events), and every rank then applies the same
+        global-norm clip + AdamW.  A rank whose shard of a ragged last batch is empty passes a 0-row ``images``.
+        Returns the GLOBAL mean loss as a device scalar (no host sync)."""
         model = self.model
         dev = model._require_cuda()
-        if noise is None:
-            noise = torch.rand(images.shape[0], model.sequence_length, device=dev)
-        loss = self._exchanged_loss_and_grads(
-            lambda scale, events, out: model.loss_and_grads(images, noise, grad_scale=scale, ready_events=events, loss_out=out), process_group)
+        rows = int(images.shape[0])
+        weight = None if global_rows is None else rows / float(global_rows)
+        if rows == 0:
+            if global_rows is None:
+                raise ValueError("an empty shard needs global_rows")
+            compute = None
+        else:
+            if noise is None:
+                noise = torch.rand(rows, model.sequence_length, device=dev)
+            compute = lambda scale, events, out: model.loss_and_grads(images, noise, grad_scale=scale, ready_events=events, loss_out=out)  # noqa: E731
+        loss = self._exchanged_loss_and_grads(compute, process_group, weight)
         self.optimizer_step(lr)
         self.global_step += 1
         self.log("train_loss", loss)
@@ -232,16 +257,19 @@ class MAEPretrainModule(nn.Module):
                 if has:
                     state[i] = {"step": torch.tensor(float(self._opt_steps)), "exp_avg": mv[name].detach().cpu().clone(),
                                 "exp_avg_sq": vv[name].detach().cpu().clone()}
-        group = {"lr": self.current_lr(), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": self.weight_decay, "amsgrad": False,
+        group = {"lr": self.current_lr(self.current_epoch + 1), "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": self.weight_decay, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "decoupled_weight_decay": True, "initial_lr": self.effective_lr,
                  "params": [i for i, _n, _h in self._named_param_index()]}
         return {"state": state, "param_groups": [group]}
 
     def lr_scheduler_state_dict(self) -> Dict[str, Any]:
-        """LambdaLR.state_dict() as Lightning stores it (the lambda itself is not picklable and is saved as None)."""
-        return {"base_lrs": [self.effective_lr], "last_epoch": self.current_epoch, "verbose": False,
-                "_step_count": self.current_epoch + 1, "_get_lr_called_within_step": False, "_last_lr": [self.current_lr()],
+        """LambdaLR.state_dict() as Lightning stores it (the lambda itself is not picklable and is saved as None).  Lightning steps
+        the epoch-interval scheduler BEFORE ModelCheckpoint runs at the end of epoch e, so the file written there carries
+        last_epoch = e + 1, _step_count = e + 2 and the learning rate of epoch e + 1 (also in the optimizer's param group)."""
+        nxt = self.current_epoch + 1
+        return {"base_lrs": [self.effective_lr], "last_epoch": nxt, "verbose": False,
+                "_step_count": nxt + 1, "_get_lr_called_within_step": False, "_last_lr": [self.current_lr(nxt)],
                 "lr_lambdas": [None]}
 
     def load_optimizer_state_dict(self, st: Dict[str, Any]) -> bool:
@@ -288,7 +316,9 @@ class MAEPretrainModule(nn.Module):
         ckpt: Dict[str, Any] = {
             "epoch": epoch, "global_step": self.global_step, "pytorch-lightning_version": "2.5.6",
             "state_dict": {f"model.{k}": t.detach().cpu().clone() for k, t in self.model.state_dict().items()},
-            "loops": {"fit_loop": {"epoch_progress": {"current": {"completed": epoch + 1, "processed": epoch + 1, "ready": epoch + 1, "started": epoch + 1}}}},
+            # Lightning's _Progress.load_state_dict reads both "total" and "current"
+            "loops": {"fit_loop": {"epoch_progress": {"total": {"completed": epoch + 1, "processed": epoch + 1, "ready": epoch + 1, "started": epoch + 1},
+                                                      "current": {"completed": epoch + 1, "processed": epoch + 1, "ready": epoch + 1, "started": epoch + 1}}}},
             "callbacks": {},
             "hyper_parameters": {"model_cfg": self.hparams["model_cfg"], "training_cfg": self.hparams["training_cfg"]},
         }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One data-parallel rank of the PRODUCT step (MAEPretrainModule.fused_training_step over libmae_hip.so), started as a
 fresh child process by tests/test_gpu_dp.py (and usable by hand).  Every rank uses cuda:0 (a one-GPU box) and the gloo
-backend; rank r takes rows [r*B/W, (r+1)*B/W) of the seeded global images and noise, runs `--steps` whole steps and
+backend; rank r takes rows [r*B/W, (r+1)*B/W) of the seeded global images and noise (B need not divide by W: the step weights the ranks by their rows), runs `--steps` whole steps and
 saves its final parameters, losses and first-step masks.  With --world 1 it is the single-process full-batch step.
 
     python tests/dp_worker.py --rank 0 --world 2 --port 29511 --out /tmp/x --config micro --precision fp32
@@ -77,13 +77,13 @@ def main() -> None:
             my_ctx, my_tgt = mdist.shard_rows(ctx, a.rank, a.world), mdist.shard_rows(tgt, a.rank, a.world)
             if step == 0:
                 keep0 = my_ctx.clone()
-            losses.append(module.fused_training_step(my_images, my_ctx, my_tgt).clone())
+            losses.append(module.fused_training_step(my_images, my_ctx, my_tgt, global_rows=B).clone())
         else:
             noise = mdist.global_noise(B, model.sequence_length, 73, step, dev)
             my_noise = mdist.shard_rows(noise, a.rank, a.world)
             if step == 0:
-                keep0 = model.random_token_mask(my_images.shape[0], my_noise)[0].cpu()
-            losses.append(module.fused_training_step(my_images, my_noise).clone())
+                keep0 = model.random_token_mask(my_images.shape[0], my_noise)[0].cpu() if my_images.shape[0] else torch.zeros(0, model.num_keep(), dtype=torch.int64)
+            losses.append(module.fused_training_step(my_images, my_noise, global_rows=B).clone())
     torch.cuda.synchronize()
     out = {"params": model.flat_params.detach().cpu(), "losses": torch.cat(losses).cpu(), "keep0": keep0,
            "target": model.target_arena.detach().cpu() if jepa else torch.zeros(1),

@@ -71,7 +71,12 @@ def test_our_checkpoint_loads_into_a_torch_adamw_and_round_trips():
     again = torch.load(f, weights_only=True)
     m2 = MAEPretrainModule(MODEL, TRAIN)
     assert m2.load_checkpoint_dict(again) == 5 and torch.equal(m2._exp_avg, module._exp_avg) and m2._opt_steps == 2
-    assert again["lr_schedulers"][0]["last_epoch"] == 4 and again["lr_schedulers"][0]["base_lrs"] == [module.effective_lr]
+    # written at the end of epoch 4, after Lightning stepped the epoch-interval scheduler: last_epoch 5, _step_count 6, lr of epoch 5
+    sch = again["lr_schedulers"][0]
+    assert sch["last_epoch"] == 5 and sch["_step_count"] == 6 and sch["base_lrs"] == [module.effective_lr]
+    assert sch["_last_lr"] == [module.current_lr(5)] and again["optimizer_states"][0]["param_groups"][0]["lr"] == module.current_lr(5)
+    prog = again["loops"]["fit_loop"]["epoch_progress"]
+    assert prog["total"]["completed"] == 5 and prog["current"]["completed"] == 5
 
 
 def test_round1_layout_and_unknown_layouts():

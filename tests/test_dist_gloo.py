@@ -123,9 +123,65 @@ def test_gradient_ready_points_follow_the_arena_layout():
     assert pts[1] < off["encoder.vit.norm.weight"] < pts[0]
 
 
-def test_shard_rows_rejects_ragged_batches():
+def test_shard_bounds_tile_any_batch():
+    """Contiguous, as-even-as-possible row shards: they tile the batch for every (rows, world), sizes differ by at most one, and a
+    rank may own nothing when the batch is shorter than the world (its step then contributes zeros to the same collectives)."""
     from ssrl_vit_mae_jepa_amd import dist as mdist
-    with pytest.raises(ValueError):
-        mdist.shard_rows(torch.zeros(7, 3), 0, 2)
-    t = torch.arange(12).reshape(6, 2)
-    assert torch.equal(torch.cat([mdist.shard_rows(t, r, 3) for r in range(3)]), t)
+    for n in (0, 1, 2, 7, 8, 9, 10, 2000, 94000 % 2000):
+        for w in (1, 2, 3, 8):
+            b = [mdist.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+    t = torch.arange(14).reshape(7, 2)
+    assert torch.equal(torch.cat([mdist.shard_rows(t, r, 2) for r in range(2)]), t)
+    assert mdist.shard_rows(t, 0, 2).shape[0] == 3 and mdist.shard_rows(t, 1, 2).shape[0] == 4
+
+
+def _ragged_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    torch.set_float32_matmul_precision("highest")
+    from oracle import mae_oracle as O
+    from ssrl_vit_mae_jepa_amd import dist as mdist
+    mdist.init_from_env(backend="gloo")
+    cfg = O.MAEConfig(image_size=32, patch_size=8, in_chans=3, embed_dim=48, depth=1, num_heads=2, decoder_embed_dim=64,
+                      decoder_depth=1, decoder_num_heads=2)
+    params = O.init_params(cfg, 73); O.randomize_params(params)
+    B = 7   # ragged over two ranks (3 + 4 rows); over three ranks of a 2-row batch rank 0 would own nothing
+    images = O.synthetic_images(B, cfg)
+    noise = mdist.global_noise(B, cfg.sequence_length, 73, 0, torch.device("cpu"))
+    lo, hi = mdist.shard_bounds(B, rank, world)
+    names = O.trainable_names(cfg)
+    n = sum(params[k].numel() for k in names)
+    flat = torch.zeros(n + 1)
+    if hi > lo:
+        loss, grads, _aux = O.loss_and_grads(params, cfg, images[lo:hi], noise[lo:hi])
+        w = (hi - lo) / B                                   # the rank's share of the global batch: what fused_training_step passes
+        flat[:n] = torch.cat([grads[k].reshape(-1) for k in names]) * w
+        flat[n] = loss * w                                  # the loss slot behind the gradients
+    mdist.allreduce_sum_(flat)
+    torch.save(flat, f"{out_dir}/ragged_r{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_batch_weighted_by_rows_equals_the_single_process_step(tmp_path):
+    """The last batch of an epoch need not divide by the world size (the reference never drops a batch, src/data.py:86-92): each
+    rank scales its mean loss and gradient by rows_local / rows_global before the one sum, which is then the gradient and the
+    loss of the whole batch.  CPU stand-in for MAEPretrainModule._exchanged_loss_and_grads(weight=...)."""
+    world, port = 2, _free_port()
+    mp.spawn(_ragged_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import mae_oracle as O
+    from ssrl_vit_mae_jepa_amd import dist as mdist
+    torch.set_float32_matmul_precision("highest")
+    cfg = O.MAEConfig(image_size=32, patch_size=8, in_chans=3, embed_dim=48, depth=1, num_heads=2, decoder_embed_dim=64,
+                      decoder_depth=1, decoder_num_heads=2)
+    params = O.init_params(cfg, 73); O.randomize_params(params)
+    images = O.synthetic_images(7, cfg)
+    noise = mdist.global_noise(7, cfg.sequence_length, 73, 0, torch.device("cpu"))
+    loss, grads, _ = O.loss_and_grads(params, cfg, images, noise)
+    want = torch.cat([torch.cat([grads[k].reshape(-1) for k in O.trainable_names(cfg)]), loss.reshape(1)])
+    r0, r1 = torch.load(tmp_path / "ragged_r0.pt"), torch.load(tmp_path / "ragged_r1.pt")
+    assert torch.equal(r0, r1)
+    assert float((r0 - want).norm() / want.norm()) < 1e-6

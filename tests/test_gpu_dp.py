@@ -77,3 +77,23 @@ def test_two_rank_product_step_equals_single_process(tmp_path, config, precision
     assert torch.equal(ov[0]["losses"], ov[1]["losses"])                                   # the global mean on every rank
     assert torch.allclose(ov[0]["losses"], one["losses"], rtol=(1e-6 if precision == "fp32" else 1e-4), atol=0)
     assert abs(float(ov[0]["stats"][0]) - float(one["stats"][0])) <= 10 * tol * float(one["stats"][0])  # global grad norm
+
+
+@pytest.mark.parametrize("config,precision,world,batch,tol", [("micro", "fp32", 2, 7, 1e-5), ("micro", "fp32", 3, 2, 1e-5), ("ijepa", "fp32", 2, 5, 2e-4)])
+def test_ragged_global_batch_equals_single_process(tmp_path, config, precision, world, batch, tol):
+    """The last batch of an epoch (the reference never drops one, src/data.py:86-92): rows that do not divide by the world size are
+    split 3 + 4, a 2-row batch over three ranks leaves rank 0 with nothing (it joins the same collectives with zeros).  Each rank
+    weights its mean by rows_local / rows_global; the result equals the single-process step on the whole batch, overlapped and
+    blocking exchange agree bit for bit, every rank reports the global mean loss."""
+    a, b, c = tmp_path / "overlap", tmp_path / "blocking", tmp_path / "single"
+    for d in (a, b, c):
+        d.mkdir()
+    ov = _run(a, world, config, precision, batch, {"MAE_DP_OVERLAP": "1", "MAE_DP_BUCKET_MB": "0.01"})
+    bl = _run(b, world, config, precision, batch, {"MAE_DP_OVERLAP": "0"})
+    one = _run(c, 1, config, precision, batch, {})[0]
+    for r in range(1, world):
+        assert torch.equal(ov[0]["params"], ov[r]["params"]) and torch.equal(ov[0]["losses"], ov[r]["losses"])
+    assert torch.equal(ov[0]["params"], bl[0]["params"]) and torch.equal(ov[0]["losses"], bl[0]["losses"])
+    assert rel_err(ov[0]["params"], one["params"]) < tol
+    assert torch.allclose(ov[0]["losses"], one["losses"], rtol=1e-5, atol=0)
+    assert torch.equal(torch.cat([o["keep0"] for o in ov]), one["keep0"])

@@ -285,7 +285,7 @@ def test_pretrain_cli_synthetic_run_and_resume(dev, tmp_path, monkeypatch):
     opt = ck["optimizer_states"][0]  # torch.optim.AdamW.state_dict() layout, indexed in parameters() order
     assert opt["param_groups"][0]["params"] == list(range(len(ck["state_dict"])))
     assert all(float(st["step"]) == ck["global_step"] for st in opt["state"].values()) and 0 not in opt["state"]  # index 0 = encoder.mask_token: no grad
-    assert ck["hyper_parameters"]["training_cfg"]["batch_size"] == 32 and ck["lr_schedulers"][0]["last_epoch"] == 1
+    assert ck["hyper_parameters"]["training_cfg"]["batch_size"] == 32 and ck["lr_schedulers"][0]["last_epoch"] == 2
     assert ck["best_val_loss"] <= ck["val_loss"]
     raw = torch.load(out / "vit-mae.pt", weights_only=True)
     assert list(raw) == list(O.param_shapes(O.YAML_TINY))  # raw state_dict, reference key names

@@ -80,3 +80,36 @@ def test_module_schedules_and_state_layout():
     assert opt["param_groups"][0]["params"] == list(range(len(list(m.model.parameters()))))
     # hand sum: context enc(36) 1.5580 + predictor 1.5047 GF forward, x3; target enc(144) 6.5186 GF forward only
     assert abs(J.flops_per_image_step(J.JEPA_VIT_S8, 36, 30) / 1e9 - 15.707) < 0.005
+
+
+def test_ema_schedule_reaches_its_end_at_the_last_real_step_and_the_sampler_state_travels():
+    """The momentum schedule is linear over total_epochs x steps_per_epoch optimizer steps: with the count the training loop really
+    runs (scripts/training/pretrain_ijepa.py sets it from its loader: STL-10 unlabeled at batch 2000 = 47 global batches per epoch,
+    the ragged last one included) it ends at ema_end exactly; with the config's fallback of 1000 it would stop at 0.9962.  The host
+    mask sampler's state is part of the checkpoint, so a resumed run continues the mask sequence."""
+    cfg_m = dict(general=dict(image_size=32, patch_size=4), encoder=dict(embed_dim=48, depth=2, num_heads=2),
+                 predictor=dict(pred_embed_dim=32, pred_depth=1, pred_num_heads=2))
+    m = IJEPAPretrainModule(cfg_m, dict(total_epochs=300, ema_start=0.996, ema_end=1.0, batch_size=2000))
+    assert m.steps_per_epoch == 1000                       # the fallback
+    m.steps_per_epoch = (94000 + 2000 - 1) // 2000         # what the CLI derives from the loader: 47
+    last = 300 * 47
+    m.global_step = last - 1
+    assert m.ema_momentum() < 1.0
+    m.global_step = last
+    assert m.ema_momentum() == 1.0
+    m.global_step = 47 * 150
+    assert abs(m.ema_momentum() - 0.998) < 1e-12
+    m.steps_per_epoch = 1000
+    m.global_step = last
+    assert abs(m.ema_momentum() - (0.996 + 0.004 * last / 300000)) < 1e-12 and m.ema_momentum() < 0.9962   # the silent failure this guards
+
+    # sampler state: draw, checkpoint, draw more; a module restored from the checkpoint draws the same "more"
+    m.global_step = 5
+    a1 = m.model.sample_masks(4, m.mask_generator)
+    ck = m.checkpoint_dict(epoch=0)
+    assert ck["mask_generator_state"].dtype == torch.uint8 and ck["steps_per_epoch"] == 1000
+    a2 = m.model.sample_masks(4, m.mask_generator)
+    m2 = IJEPAPretrainModule(cfg_m, dict(total_epochs=300, ema_start=0.996, ema_end=1.0, batch_size=2000))
+    m2.load_checkpoint_dict(ck)
+    b2 = m2.model.sample_masks(4, m2.mask_generator)
+    assert torch.equal(a2[0], b2[0]) and torch.equal(a2[1], b2[1]) and not (a1[0].shape == a2[0].shape and torch.equal(a1[0], a2[0]) and torch.equal(a1[1], a2[1]))
