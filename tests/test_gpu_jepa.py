@@ -153,6 +153,47 @@ def test_full_size_properties_vits8_b2000(dev):
     assert torch.equal(la, lb) and torch.equal(gu, model.flat_grads)
 
 
+def test_full_size_properties_vitl14_b256(dev):
+    """BASELINE.json configs[4] at its per-GPU size: ViT-L/14 224 px (depth 24, width 1024, 16 heads), predictor 384 x 12 x 12 heads,
+    batch 256, bf16 -- the whole step at full depth (the oracle parity of these shapes runs at depth 2 + 1 below).  The same
+    size-independent properties as the ViT-S/8 test: finite loss and gradients, linearity in the gradient scale, the two halves of
+    the batch summing to the whole (what the data-parallel exchange relies on), and one fused step that moves the context
+    encoder, keeps the EMA target between its old value and the new context encoder, and lowers nothing to NaN."""
+    cfg, B = J.JEPA_VIT_L14, 256
+    assert (cfg.depth, cfg.pred_depth, cfg.embed_dim, cfg.image_size, cfg.patch_size) == (24, 12, 1024, 224, 14)
+    mc = model_cfg(cfg, "bf16")
+    torch.manual_seed(1)
+    tcfg = dict(total_epochs=300, warmup_epochs=15, steps_per_epoch=1000, batch_size=2048, base_learning_rate=1.5e-4, weight_decay=0.05, ema_start=0.996, ema_end=1.0)
+    module = IJEPAPretrainModule(mc, tcfg).to(dev)
+    model = module.model
+    g = torch.Generator(device=dev).manual_seed(73)
+    images = torch.rand(B, 3, 224, 224, device=dev, generator=g) * 2 - 1
+    ctx, tgt = model.sample_masks(B, torch.Generator().manual_seed(5))
+    assert tgt.shape[:2] == (B, 4) and ctx.shape[1] >= 1 and int(ctx.max()) <= 256 and int(tgt.max()) <= 256
+    l1 = model.loss_and_grads(images, ctx, tgt).clone()
+    g1 = model.flat_grads.clone()
+    assert torch.isfinite(l1).all() and torch.isfinite(g1).all() and g1.norm().item() > 0 and 0.05 < l1.item() < 20
+    l2 = model.loss_and_grads(images, ctx, tgt, grad_scale=0.5)
+    assert abs(l2.item() - l1.item()) <= 1e-5 * abs(l1.item()) and rel_err(model.flat_grads, 0.5 * g1) < 2e-2
+    h = B // 2
+    model.loss_and_grads(images[:h].contiguous(), ctx[:h], tgt[:h], grad_scale=0.5)
+    ga = model.flat_grads.clone()
+    model.loss_and_grads(images[h:].contiguous(), ctx[h:], tgt[h:], grad_scale=0.5)
+    assert rel_err(ga + model.flat_grads, g1) < 3e-2
+    # one fused step (AdamW without clipping + EMA in the same sweep)
+    p0 = model.net.flat_params.clone()
+    tsd0 = {k: v.clone() for k, v in model.target_state_dict().items()}
+    module.on_train_epoch_start()
+    loss = module.fused_training_step(images, ctx, tgt)
+    assert torch.isfinite(loss).all() and torch.isfinite(model.net.flat_params).all() and torch.isfinite(model.target_arena).all()
+    moved = (model.net.flat_params - p0).abs().max().item()
+    assert 0 < moved < 1e-2                                             # lr = 1.2e-3 x warm-up factor 1/15
+    sd, tsd = model.net.state_dict(), model.target_state_dict()
+    for n in ("encoder.vit.patch_embed.proj.weight", "encoder.vit.blocks.0.attn.qkv.weight", "encoder.vit.blocks.23.mlp.fc2.weight", "encoder.vit.norm.weight"):
+        assert rel_err(tsd[n], 0.996 * tsd0[n] + 0.004 * sd[n]) < 1e-5, n   # momentum at step 0 = ema_start
+        assert not torch.equal(tsd[n], tsd0[n]), n
+
+
 @pytest.mark.parametrize("prec,tol_loss,tol_grad", [("fp32", 1e-4, 3e-4), ("bf16", 5e-3, 5e-2)])
 def test_vitl14_geometry_matches_oracle(dev, prec, tol_loss, tol_grad):
     """BASELINE.json configs[4] shapes (ViT-L/14 224 px: 256 patches of 14 x 14, width 1024, 16 heads of 64; predictor 384 wide,
