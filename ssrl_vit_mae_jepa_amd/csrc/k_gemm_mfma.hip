@@ -862,6 +862,241 @@ __global__ void __launch_bounds__(512, 2) gemm_tn3_kernel(TnGroup grp, int64_t M
   }
 }
 
+// ---- round 3: the same kernel with buffer DMA (scalar step offset, range-checked rows), the six pieces of a step issued in pairs
+// between thirds of phase A's MFMAs instead of in one burst at the top of the step, and no special cases in the step (MAE_WGRAD=v4)
+template <bool BURST>
+__global__ void __launch_bounds__(512, 2) gemm_tn4_kernel(TnGroup grp, int64_t M, int64_t split_stride, int64_t m_chunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int vb = (int)xcd_remap(blockIdx.x, gridDim.x);
+  const int gtile = vb % grp.total_tiles;
+  const int split = vb / grp.total_tiles;
+  const bool second = grp.nprob > 1 && gtile >= grp.p[1].tile_begin;   // workgroup-uniform
+  const bf16* __restrict__ dY = second ? grp.p[1].dY : grp.p[0].dY;
+  const bf16* __restrict__ X = second ? grp.p[1].X : grp.p[0].X;
+  float* __restrict__ out = second ? grp.p[1].out : grp.p[0].out;
+  float* __restrict__ db = second ? grp.p[1].db : grp.p[0].db;
+  const int N = second ? grp.p[1].N : grp.p[0].N, K = second ? grp.p[1].K : grp.p[0].K;
+  const int tiles_k = second ? grp.p[1].tiles_k : grp.p[0].tiles_k;
+  const int tile = gtile - (second ? grp.p[1].tile_begin : 0);
+  const int n0 = (tile / tiles_k) * T2, k0 = (tile % tiles_k) * T2;
+  const int64_t mbeg = (int64_t)split * m_chunk;
+  const int64_t mend = mbeg + m_chunk < M ? mbeg + m_chunk : M;
+  const int nsteps = mend > mbeg ? (int)((mend - mbeg + T2_BR - 1) / T2_BR) : 0;
+
+  // ---- producer side (round 3): buffer DMA with one scalar offset per step.  Waves 0-3 fetch X rows, waves 4-7 dY rows; a lane's six
+  // (row, chunk) offsets never change; rows past the split's end are out of the descriptor's range and arrive as zeros (no clamp, no
+  // zero-fill pass for a ragged last step); the stream is never switched off (phantom pieces past the last step land in a stage
+  // nobody reads any more), so every step waits with the same count.
+  const bool isY = wave >= 4;
+  const int64_t ld = isY ? N : K;
+  const uint32_t ldb = (uint32_t)ld * 2u;
+  typedef __attribute__((ext_vector_type(4))) int i32x4_;
+  const uint64_t gaddr = (uint64_t)(uintptr_t)(isY ? dY : X);
+  const i32x4_ rsrc = i32x4_{(int)(uint32_t)gaddr, (int)(uint32_t)((gaddr >> 32) & 0xffffu), (int)((uint32_t)mend * ldb), 0x00020000};
+  uint32_t vo[T2_GPW];
+#pragma unroll
+  for (int q = 0; q < T2_GPW; ++q) {
+    const int c = ((wave & 3) * T2_GPW + q) * 64 + lane;
+    const int row = c / T2_CPR, slot = c % T2_CPR;
+    int sc = ((((slot >> 1) ^ ((row >> 1) & 3)) << 1) | (slot & 1)) * 8;
+    // a last tile column that sticks out of the matrix (widths that are not multiples of 192): its chunks are fetched from the
+    // tile's first column instead (valid memory); they only ever reach accumulators whose stores are guarded out below
+    if (sc >= (isY ? N - n0 : K - k0)) sc = 0;
+    vo[q] = (uint32_t)row * ldb + (uint32_t)((isY ? n0 : k0) + sc) * 2u;
+  }
+  uint32_t soff = (uint32_t)mbeg * ldb;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem) + (uint32_t)((isY ? T2_HALF : 0) + (wave & 3) * (T2_GPW * 1024));
+  uint32_t ldst = lds0;
+  auto issue_piece = [&](int q) {
+#ifndef MAE_DBG_TN_NO_LOAD
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(ldst + (uint32_t)(q * 1024)), "v"(vo[q]), "s"(rsrc), "s"(soff) : "memory");
+#endif
+  };
+  auto issue_next = [&]() {
+    soff += (uint32_t)T2_BR * ldb;
+    ldst = ldst == lds0 + (uint32_t)((T2_NSTAGE - 1) * T2_STAGE) ? lds0 : ldst + (uint32_t)T2_STAGE;
+  };
+
+  f32x4 acc[T2_KI][T2_NI], accb[T2_NI];
+#pragma unroll
+  for (int i = 0; i < T2_KI; ++i)
+#pragma unroll
+    for (int j = 0; j < T2_NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < T2_NI; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = db != nullptr && k0 == 0 && wk == 0;
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
+
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p = lane & 3;
+  const int sw = ((g & 1) << 1) | (q4 >> 1);
+  const int lane_off = (4 * g + q4) * T2_RS + p * 8;
+  int yo[T2_NI], xo[T2_KI];
+#pragma unroll
+  for (int ni = 0; ni < T2_NI; ++ni) yo[ni] = T2_HALF + lane_off + (((wn * T2_NI + ni) ^ sw) * 32);
+#pragma unroll
+  for (int ki = 0; ki < T2_KI; ++ki) xo[ki] = lane_off + (((wk * T2_KI + ki) ^ sw) * 32);
+
+  bf16x8 yf[2][T2_NI], xf[2][T2_KI];
+#define TN3_READ(sb, h)                                                                                 \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni) {                                              \
+      const bf16x4 lo = lds_read_tr((sb) + yo[ni] + (32 * (h)) * T2_RS);                                \
+      const bf16x4 hi = lds_read_tr((sb) + yo[ni] + (32 * (h) + 16) * T2_RS);                           \
+      yf[h][ni] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                       \
+    }                                                                                                   \
+    _Pragma("unroll") for (int ki = 0; ki < T2_KI; ++ki) {                                              \
+      const bf16x4 lo = lds_read_tr((sb) + xo[ki] + (32 * (h)) * T2_RS);                                \
+      const bf16x4 hi = lds_read_tr((sb) + xo[ki] + (32 * (h) + 16) * T2_RS);                           \
+      xf[h][ki] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                       \
+    }                                                                                                   \
+  }
+#ifdef MAE_DBG_TN_NO_MFMA
+#define TN3_MFMA(h) { asm volatile("" :: "v"(xf[h][0]), "v"(xf[h][1]), "v"(xf[h][2]), "v"(xf[h][3]), "v"(xf[h][4]), "v"(xf[h][5]), "v"(yf[h][0]), "v"(yf[h][1]), "v"(yf[h][2])); }
+#else
+#define TN3_MFMA(h)                                                                                     \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ki = 0; ki < T2_KI; ++ki)                                                \
+      _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                              \
+        acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[h][ki], yf[h][ni], acc[ki][ni], 0, 0, 0); \
+  }
+#endif
+#define TN3_BIAS(h)                                                                                     \
+  if (do_bias) {                                                                                        \
+    _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                                \
+      accb[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, yf[h][ni], accb[ni], 0, 0, 0);           \
+  }
+#if defined(MAE_DBG_TN3_NOSCHED) || defined(MAE_DBG_TN_NO_MFMA)
+#define TN3_INTERLEAVE() {}
+#else
+#define TN3_INTERLEAVE()                                                                                \
+  {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < T2_KI * T2_NI; ++i) {                                         \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
+    }                                                                                                   \
+  }
+#endif
+#define TN4_STEP_TOP()                                                                                  \
+    tn_wait_vm<T2_GPW>();                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's reads of the stage refilled below have landed */ \
+    __builtin_amdgcn_s_barrier();                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    asm volatile("" ::: "memory");                                                                        \
+    const char* sb = smem + cs * T2_STAGE;                                                                \
+    if (BURST) {                                                                                          \
+      _Pragma("unroll") for (int q = 0; q < T2_GPW; ++q) issue_piece(q);                                  \
+      issue_next();                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }
+  // a third of phase A: three fragments of half 0 are read beside six MFMAs of the previous step's half 1, then two DMA pieces go out
+#define TN4_READ_Y(sb, h)                                                                               \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni) {                                              \
+      const bf16x4 lo = lds_read_tr((sb) + yo[ni] + (32 * (h)) * T2_RS);                                \
+      const bf16x4 hi = lds_read_tr((sb) + yo[ni] + (32 * (h) + 16) * T2_RS);                           \
+      yf[h][ni] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                       \
+    }                                                                                                   \
+  }
+#define TN4_READ_X(sb, h, K0, K1)                                                                       \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ki = (K0); ki < (K1); ++ki) {                                            \
+      const bf16x4 lo = lds_read_tr((sb) + xo[ki] + (32 * (h)) * T2_RS);                                \
+      const bf16x4 hi = lds_read_tr((sb) + xo[ki] + (32 * (h) + 16) * T2_RS);                           \
+      xf[h][ki] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                       \
+    }                                                                                                   \
+  }
+#define TN4_MFMA(h, K0, K1)                                                                             \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ki = (K0); ki < (K1); ++ki)                                              \
+      _Pragma("unroll") for (int ni = 0; ni < T2_NI; ++ni)                                              \
+        acc[ki][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[h][ki], yf[h][ni], acc[ki][ni], 0, 0, 0); \
+  }
+#define TN4_IL6()                                                                                       \
+  {                                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                \
+    }                                                                                                   \
+  }
+#define TN4_PHASE_A(sb)                                                                                 \
+    TN4_READ_Y(sb, 0) TN4_MFMA(1, 0, 2) TN4_IL6()                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (!BURST) { issue_piece(0); issue_piece(1); }                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    TN4_READ_X(sb, 0, 0, 3) TN4_MFMA(1, 2, 4) TN4_IL6()                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (!BURST) { issue_piece(2); issue_piece(3); }                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    TN4_READ_X(sb, 0, 3, 6) TN4_MFMA(1, 4, 6) TN4_IL6()                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if (!BURST) { issue_piece(4); issue_piece(5); issue_next(); }                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    TN3_BIAS(1)                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+  int cs = 0;
+  if (nsteps > 0) {
+    // two steps of DMA in flight before the first wait
+#pragma unroll
+    for (int q = 0; q < T2_GPW; ++q) issue_piece(q);
+    issue_next();
+#pragma unroll
+    for (int q = 0; q < T2_GPW; ++q) issue_piece(q);
+    issue_next();
+    {  // step 0: nothing to multiply yet while the first half is read (the fragments of "the previous half 1" are zeros)
+      const bf16 z = (bf16)0.0f;
+      const bf16x8 zz = bf16x8{z, z, z, z, z, z, z, z};
+#pragma unroll
+      for (int ni = 0; ni < T2_NI; ++ni) yf[1][ni] = zz;
+#pragma unroll
+      for (int ki = 0; ki < T2_KI; ++ki) xf[1][ki] = zz;
+    }
+    for (int st = 0; st < nsteps; ++st) {
+      TN4_STEP_TOP()
+      TN4_PHASE_A(sb)
+      TN3_READ(sb, 1)
+      TN3_MFMA(0)
+      TN3_INTERLEAVE()
+      __builtin_amdgcn_sched_barrier(0);
+      TN3_BIAS(0)
+      cs = cs == T2_NSTAGE - 1 ? 0 : cs + 1;
+    }
+    TN3_MFMA(1)
+    TN3_BIAS(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the phantom pieces issued past the last step land before the LDS is released
+  }
+#undef TN4_PHASE_A
+#undef TN4_IL6
+#undef TN4_MFMA
+#undef TN4_READ_X
+#undef TN4_READ_Y
+#undef TN4_STEP_TOP
+#undef TN3_INTERLEAVE
+#undef TN3_BIAS
+#undef TN3_MFMA
+#undef TN3_READ
+  float* o = out + (int64_t)split * split_stride;
+  if (do_bias && lane < 16) {
+#pragma unroll
+    for (int ni = 0; ni < T2_NI; ++ni) {
+      const int n = n0 + wn * (T2_NI * 16) + ni * 16 + lane;
+      if (n < N) db[(int64_t)split * split_stride + n] = accb[ni][0];
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < T2_NI; ++ni) {
+    const int n = n0 + wn * (T2_NI * 16) + ni * 16 + (lane & 15);
+#pragma unroll
+    for (int ki = 0; ki < T2_KI; ++ki) {
+      const int k = k0 + wk * (T2_KI * 16) + ki * 16 + (lane >> 4) * 4;
+      if (n < N && k < K) store4(o + (int64_t)n * K + k, acc[ki][ni]);
+    }
+  }
+}
+
 // the 192 x 192 ring kernels: every width that is a multiple of 192, and (v3 only, whose loads and stores are guarded by column)
 // widths that fill their last tile column well enough -- 1024 = 5.33 tiles, 512 x 2048 = 3 x 11 tiles at 86 % -- to beat the
 // 128 x 128 register-staged kernel (measured 0.55-0.70 PF/s at 1024-wide layers against 0.9 PF/s x fill for this one)
@@ -951,6 +1186,9 @@ __global__ void __launch_bounds__(256) slab_reduce_group_kernel(const float* __r
   }
 }
 
+// the buffer-DMA kernel addresses a matrix with 32-bit byte offsets (two steps of phantom rows past the end included)
+static bool tn4_range_ok(int64_t M, int N, int K) { return (M + 4 * T2_BR) * (int64_t)std::max(N, K) * 2 < ((int64_t)1 << 32); }
+
 static int wgrad_splits(int64_t M, int N, int K) {
   const int tn = N % 128 == 0 || N % 64 != 0 ? 128 : 64, tk = K % 128 == 0 || K % 64 != 0 ? 128 : 64;  // ragged dims take 128-wide tiles
   const int64_t tiles = (int64_t)cdiv(N, tn) * cdiv(K, tk);
@@ -993,14 +1231,18 @@ int mfma_linear_wgrad(const bf16* dY, const bf16* X, int64_t M, int N, int K, fl
   if (v2) {
     const int tiles_n = (int)cdiv(N, T2), tiles_k = (int)cdiv(K, T2);
     const int lds = T2_NSTAGE * T2_STAGE;
-    const char* ev = getenv("MAE_WGRAD");  // A/B switch (tools/gemm_bench.py --wgrad): v2 | v2r | v3 | v3r (default); r = DMA issued from inline asm
-    const bool sel = ev && ev[0] == 'v' && (ev[1] == '2' || ev[1] == '3');
-    const bool k3 = !sel || ev[1] == '3', raw = !sel || ev[2] == 'r';
+    // A/B switch (tools/gemm_bench.py --wgrad): v2 | v2r | v3 | v3r | v4 | v4b; default = v4 (buffer DMA), burst issue (v4b) for the 192-wide
+    // HBM-bound decoder shapes, v3r where a matrix is beyond 32-bit byte offsets
+    const char* ev = getenv("MAE_WGRAD");
+    const bool sel = ev && ev[0] == 'v' && (ev[1] == '2' || ev[1] == '3' || ev[1] == '4');
+    const bool k4 = (!sel || ev[1] == '4') && tn4_range_ok(M, N, K);
+    const bool burst = sel && ev[1] == '4' ? ev[2] == 'b' : std::min(N, K) <= T2;
+    const bool k3 = !sel || ev[1] == '3' || k4, raw = !sel || ev[1] == '4' || ev[2] == 'r';
     if (k3) {
       TnGroup g{};
       g.p[0] = TnProb{dY, X, out, dbo, N, K, tiles_k, 0};
       g.nprob = 1; g.total_tiles = tiles_n * tiles_k;
-      auto kern = raw ? gemm_tn3_kernel<true> : gemm_tn3_kernel<false>;
+      auto kern = k4 ? (burst ? gemm_tn4_kernel<true> : gemm_tn4_kernel<false>) : (raw ? gemm_tn3_kernel<true> : gemm_tn3_kernel<false>);
       MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       hipLaunchKernelGGL(kern, dim3((unsigned)(g.total_tiles * S)), dim3(512), lds, s, g, M, stride, m_chunk);
     } else {
@@ -1069,7 +1311,10 @@ int mfma_linear_wgrad_pair(const bf16* dY0, const bf16* X0, int N0, int K0, floa
   g.p[1] = TnProb{dY1, X1, base + nk0 + N0, base + nk0 + N0 + nk1, N1, K1, tk1, tn0 * tk0};
   g.nprob = 2; g.total_tiles = tn0 * tk0 + tn1 * tk1;
   const int lds = T2_NSTAGE * T2_STAGE;
-  auto kern = gemm_tn3_kernel<true>;
+  const char* pv = getenv("MAE_WGRAD_PAIR");   // A/B: "3" the pointer-DMA kernel, "4" / "4b" the buffer-DMA kernel with spread / burst issue
+  const bool k4 = !(pv && pv[0] == '3') && tn4_range_ok(M, N0, K0) && tn4_range_ok(M, N1, K1);
+  const bool burst = pv && pv[0] == '4' ? pv[1] == 'b' : std::min(std::min(N0, K0), std::min(N1, K1)) <= T2;
+  auto kern = k4 ? (burst ? gemm_tn4_kernel<true> : gemm_tn4_kernel<false>) : gemm_tn3_kernel<true>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(g.total_tiles * S)), dim3(512), lds, s, g, M, stride, m_chunk);
   MAE_LAUNCH_CHECK();

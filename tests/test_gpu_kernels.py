@@ -272,6 +272,49 @@ def test_linear_wgrad_pair(dev, M, s0, s1, dt):
         assert rel_err(dW, ref) < 2e-5 and rel_err(db, refb) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(8200, 1536, 384), (6000, 384, 1536), (4289, 576, 192), (20000, 1152, 384), (4097, 192, 192), (5000, 512, 1024),
+                                   (4100, 328, 200), (4931, 768, 768), (577, 384, 192)])
+def test_wgrad_buffer_dma_kernel_is_bit_identical_to_the_pointer_dma_kernel(dev, M, N, K, monkeypatch):
+    """Round 3's gemm_tn4_kernel (range-checked buffer DMA, no clamp / zero-fill pass for a ragged last step, pieces issued between
+    MFMA thirds or in a burst) sums the same products in the same order as gemm_tn3_kernel: every M-split's ragged tail, a last
+    tile column that sticks out of the matrix, and the bias column agree bit for bit."""
+    g = G(M * 3 + N + K)
+    dY = dv(torch.randn(M, N, generator=g).to(torch.bfloat16)); A = dv(torch.randn(M, K, generator=g).to(torch.bfloat16))
+    scratch = torch.zeros(lib.mae_linear_wgrad_scratch_bytes(M, N, K), dtype=torch.uint8, device=dev)
+    res = {}
+    for v in ("v3r", "v4", "v4b"):
+        monkeypatch.setenv("MAE_WGRAD", v)
+        dW = torch.full((N, K), float("nan"), device=dev); db = torch.full((N,), float("nan"), device=dev)
+        check(lib.mae_linear_wgrad(_ptr(dY), _ptr(A), M, N, K, BF16, _ptr(dW), _ptr(db), _ptr(scratch), stream(dev)))
+        torch.cuda.synchronize()
+        res[v] = (dW, db)
+    assert not torch.isnan(res["v3r"][0]).any()
+    for v in ("v4", "v4b"):
+        assert torch.equal(res[v][0], res["v3r"][0]) and torch.equal(res[v][1], res["v3r"][1]), v
+
+
+@pytest.mark.parametrize("M,s0,s1", [(9000, (384, 1536), (1536, 384)), (8300, (384, 384), (1152, 384)), (8197, (192, 192), (576, 192)), (9001, (512, 1024), (1536, 512))])
+def test_wgrad_pair_buffer_dma_kernel_is_bit_identical(dev, M, s0, s1, monkeypatch):
+    g = G(M + s0[0])
+    ops = []
+    for N, K in (s0, s1):
+        ops.append((dv(torch.randn(M, N, generator=g).to(torch.bfloat16)), dv(torch.randn(M, K, generator=g).to(torch.bfloat16)), N, K))
+    scratch = torch.zeros(lib.mae_linear_wgrad_pair_scratch_bytes(M, *s0, *s1), dtype=torch.uint8, device=dev)
+    res = {}
+    for mode in ("3", "4", "4b"):
+        monkeypatch.setenv("MAE_WGRAD_PAIR", mode)
+        outs = [(torch.full((N, K), float("nan"), device=dev), torch.full((N,), float("nan"), device=dev)) for _, _, N, K in ops]
+        (y0, a0, N0, K0), (y1, a1, N1, K1) = ops
+        check(lib.mae_linear_wgrad_pair(_ptr(y0), _ptr(a0), N0, K0, _ptr(outs[0][0]), _ptr(outs[0][1]), _ptr(y1), _ptr(a1), N1, K1, _ptr(outs[1][0]), _ptr(outs[1][1]),
+                                        M, BF16, _ptr(scratch), stream(dev)))
+        torch.cuda.synchronize()
+        res[mode] = outs
+    assert not any(torch.isnan(t).any() for pr in res["3"] for t in pr)
+    for mode in ("4", "4b"):
+        for (w, b), (w3, b3) in zip(res[mode], res["3"]):
+            assert torch.equal(w, w3) and torch.equal(b, b3), mode
+
+
 # ----------------------------------------------------------------------------------------------- attention
 def _attn_ref(qkv, B, T, H, hd):
     q, k, v = qkv.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)

@@ -120,8 +120,15 @@ def wgrad_pair_main(args, dev):
         def run(mode):
             os.environ["MAE_WGRAD_PAIR"] = mode
             check(lib.mae_linear_wgrad_pair(_ptr(y0), _ptr(a0), N0, K0, _ptr(w0), _ptr(b0), _ptr(y1), _ptr(a1), N1, K1, _ptr(w1), _ptr(b1), M, BF16, _ptr(scratch), stream(dev)))
-        for mode in ("1", "0"):
+        ref = None
+        for mode in ("3", "4", "4b", "1", "0"):
             run(mode); torch.cuda.synchronize()
+            outs = [x.clone() for x in (w0, b0, w1, b1)]
+            if ref is None:
+                ref = outs
+            elif mode[0] == "4":
+                same = all(torch.equal(a, b) for a, b in zip(ref, outs))
+                print(f"  pair kernel tn{mode} bitwise equal to tn3: {same}", flush=True)
             ts = []
             for _ in range(args.rounds):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -129,7 +136,7 @@ def wgrad_pair_main(args, dev):
                 ts.append(e0.elapsed_time(e1) * 1e3)
             t[mode] = sorted(ts)[len(ts) // 2]
         fl = 2.0 * M * (N0 * K0 + N1 * K1)
-        print(f"{name:16s} M={M} | paired: {t['1']:7.1f} us {fl / t['1'] / 1e6:5.0f} TF/s | two launches: {t['0']:7.1f} us {fl / t['0'] / 1e6:5.0f} TF/s", flush=True)
+        print(f"{name:16s} M={M} | paired (default): {t['1']:7.1f} us {fl / t['1'] / 1e6:5.0f} TF/s | tn3: {t['3']:7.1f} us | tn4: {t['4']:7.1f} us {fl / t['4'] / 1e6:5.0f} TF/s | tn4 burst: {t['4b']:7.1f} us | two launches: {t['0']:7.1f} us {fl / t['0'] / 1e6:5.0f} TF/s", flush=True)
     os.environ.pop("MAE_WGRAD_PAIR", None)
 
 
