@@ -124,6 +124,17 @@ __device__ __forceinline__ void first_generation_stagger(int stagger, int gen1) 
   }
 }
 
+// Workgroup -> (image, head).  The hardware deals consecutive blockIdx round-robin over the 8 XCDs (one L2 each).  With 32-wide heads a
+// 128-byte line of a qkv / out / d_out row belongs to TWO heads: dealt in blockIdx order they land on different XCDs and the line is
+// fetched from HBM twice (PMC, round 2: decoder attention moved 1.75x its algorithmic bytes).  The remap gives XCD x the contiguous
+// range [x G/8, (x+1) G/8) of (image, head) pairs, so the two heads of a line run on the same L2 within a few dispatches of each other.
+__device__ __forceinline__ int att_block(int remap) {
+  if (!remap) return (int)blockIdx.x;
+  const int nb = (int)gridDim.x, bid = (int)blockIdx.x;
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
 // Threads per block: one wave per 16-token tile while the variant's registers allow 4 waves per SIMD (<= 128 VGPRs);
 // the wide unrolled variants keep 8 waves and walk their tiles in passes.
 template <int HD> struct FwdCap { static constexpr int v = 512; };  // (10 waves for the 145-token decoder forward measured 12 % slower than 5 waves x 2 passes)
@@ -131,14 +142,15 @@ template <int NCH> struct BwdCap { static constexpr int v = NCH == 0 ? 1024 : 51
 
 template <int HD, int NCH>
 __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
-                                                            bf16* __restrict__ out, float* __restrict__ lse, int stagger, int gen1, int hdv) {
+                                                            bf16* __restrict__ out, float* __restrict__ lse, int stagger, int gen1, int hdv, int remap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   first_generation_stagger(stagger, gen1);
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
   char* sK = sQ + img;
   char* sV = sK + img;
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int vb = att_block(remap);
+  const int b = vb / H, h = vb - b * H;
   const int64_t gs = 3ll * H * hdv;  // hdv = head dim in memory (<= HD)
   const int cprv = hdv >> 3;
   const bf16* base = qkv + (int64_t)b * T * gs + h * hdv;
@@ -264,7 +276,7 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
 template <int HD, int NCH>
 __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
-                                                            int Tp, int H, float scale, bf16* __restrict__ d_qkv, int stagger, int gen1, int hdv) {
+                                                            int Tp, int H, float scale, bf16* __restrict__ d_qkv, int stagger, int gen1, int hdv, int remap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   first_generation_stagger(stagger, gen1);
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
@@ -274,7 +286,8 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   char* sdO = sV + img;
   float* sLse = reinterpret_cast<float*>(sdO + img);  // pre-multiplied by log2(e); 1e30 on padded rows
   float* sD = sLse + Tp;
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int vb = att_block(remap);
+  const int b = vb / H, h = vb - b * H;
   const int64_t gs = 3ll * H * hdv, os = (int64_t)H * hdv;  // hdv = head dim in memory (<= HD)
   const int cprv = hdv >> 3;
   const bf16* base = qkv + (int64_t)b * T * gs + h * hdv;
@@ -471,6 +484,10 @@ static int attn_waves(int T, int max_threads) {
   return (nt + passes - 1) / passes;  // <= maxw waves, balanced over the 16-token tiles
 }
 
+static int attn_remap() {   // MAE_ATT_XCD=0: blockIdx order (A/B)
+  static const int v = [] { const char* e = getenv("MAE_ATT_XCD"); return e ? atoi(e) : 1; }();
+  return v;
+}
 static int attn_stagger() {
   static const int v = [] { const char* e = getenv("MAE_ATT_STAGGER"); return e ? atoi(e) : 0; }();
   return v;
@@ -489,7 +506,7 @@ template <int HD, int NCH>
 static int launch_attn_fwd(const bf16* qkv, int B, int T, int Tp, int H, int hdv, size_t lds, float scale, bf16* out, float* lse, hipStream_t s) {
   auto kern = attn_fwd_mfma_kernel<HD, NCH>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, FwdCap<HD>::v)), lds, s, qkv, T, Tp, H, scale, out, lse, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, FwdCap<HD>::v)), hdv);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, FwdCap<HD>::v)), lds, s, qkv, T, Tp, H, scale, out, lse, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, FwdCap<HD>::v)), hdv, attn_remap());
   MAE_LAUNCH_CHECK();
   return 0;
 }
@@ -498,7 +515,7 @@ static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, 
                            float scale, bf16* d_qkv, hipStream_t s) {
   auto kern = attn_bwd_mfma_kernel<HD, NCH>;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, BwdCap<NCH>::v)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, BwdCap<NCH>::v)), hdv);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, BwdCap<NCH>::v)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, BwdCap<NCH>::v)), hdv, attn_remap());
   MAE_LAUNCH_CHECK();
   return 0;
 }

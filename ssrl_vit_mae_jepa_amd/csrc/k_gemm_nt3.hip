@@ -471,8 +471,10 @@ static int launch_nt3(const bf16* A, const bf16* W, int64_t M, int N, int K, con
   MAE_REQUIRE(T < (1ll << 30), "gemm: too many tiles");
   const int tiles_m = (int)cdiv(M, G_::BM), tiles_n = N / G_::BN;
   const int grid = (int)std::min<int64_t>(T, (int64_t)num_cus() * (WM == 4 ? 1 : 2));  // persistent: one 8-wave or two 4-wave workgroups per CU
-  // activation rows that few workgroups share are streamed with the non-temporal policy (MAE_NT3_ANT = largest tiles_n that gets it; A/B)
-  static const int ant_max = [] { const char* v = getenv("MAE_NT3_ANT"); return v ? atoi(v) : 0; }();
+  // activation rows that a single workgroup reads (tiles_n == 1: the 192-wide decoder outputs) are streamed with the non-temporal policy:
+  // cold, those shapes run 15-21 % faster (profiles/r03_nt3_kloop.txt); panels shared by several tile columns must stay in L2.
+  // MAE_NT3_ANT = largest tiles_n that gets the policy (0 = never; A/B)
+  static const int ant_max = [] { const char* v = getenv("MAE_NT3_ANT"); return v ? atoi(v) : 1; }();
   const int a_nt = tiles_n <= ant_max ? 1 : 0;
   if (e.bias) {
     auto kern = gemm_nt3_kernel<MODE, TO, true, NI, MI, WM>;

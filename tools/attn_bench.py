@@ -6,7 +6,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch  # noqa: E402
 from tests.util import BF16, check, lib, stream, _ptr  # noqa: E402
 
-SHAPES = [("enc  T=36  hd=64", 2000, 36, 6, 64), ("dec  T=145 hd=32", 2000, 145, 6, 32), ("2b   T=145 hd=64", 1000, 145, 8, 64)]
+SHAPES = [("enc  T=36  hd=64", 2000, 36, 6, 64), ("dec  T=145 hd=32", 2000, 145, 6, 32), ("2b   T=145 hd=64", 1000, 145, 8, 64),
+          ("vitb enc T=50 hd=64", 512, 50, 12, 64), ("vitb dec T=197 hd=32", 512, 197, 16, 32), ("vitl T=257 hd=64", 256, 257, 16, 64)]
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(1)
 for name, B, T, H, hd in SHAPES:
