@@ -273,7 +273,18 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
   }
 }
 
-template <int HD, int NCH>
+// PH = 0: both phases from four staged images (Q, K, V, dO).  Sequences whose four images do not fit the LDS run as TWO launches that stage
+// two images each and take their own 16-token tile's fragments straight from global memory: PH = 1 (dQ: K, V staged) and PH = 2 (dK / dV:
+// Q, dO staged).  Same arithmetic in the same order as PH = 0.
+// row fragment of the caller's own tile straight from global memory (rows past T clamp to T - 1: masked or multiplied by zero downstream)
+template <int HD>
+__device__ __forceinline__ bf16x8 rowfrag_global(const bf16* g, int64_t gs, int row0, int ks, int lane, int T) {
+  int row = row0 + (lane & 15);
+  row = row < T ? row : T - 1;
+  return *reinterpret_cast<const bf16x8*>(g + row * gs + ks * 32 + 8 * (lane >> 4));
+}
+
+template <int HD, int NCH, int PH = 0>
 __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
                                                             int Tp, int H, float scale, bf16* __restrict__ d_qkv, int stagger, int gen1, int hdv, int remap) {
@@ -281,10 +292,10 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   first_generation_stagger(stagger, gen1);
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
-  char* sK = sQ + img;
+  char* sK = PH == 1 ? smem : sQ + img;
   char* sV = sK + img;
-  char* sdO = sV + img;
-  float* sLse = reinterpret_cast<float*>(sdO + img);  // pre-multiplied by log2(e); 1e30 on padded rows
+  char* sdO = PH == 2 ? smem + img : sV + img;
+  float* sLse = reinterpret_cast<float*>(smem + (PH == 0 ? 4 : 2) * img);  // pre-multiplied by log2(e); 1e30 on padded rows
   float* sD = sLse + Tp;
   const int vb = att_block(remap);
   const int b = vb / H, h = vb - b * H;
@@ -296,17 +307,17 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   bf16* dbase = d_qkv + (int64_t)b * T * gs + h * hdv;
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane, cprv);
-  stage_image_dma<HD>(sK, img, base + os, gs, T, wave, nwaves, lane, cprv);
-  stage_image_dma<HD>(sV, img, base + 2 * os, gs, T, wave, nwaves, lane, cprv);
-  stage_image_dma<HD>(sdO, img, dobase, os, T, wave, nwaves, lane, cprv);
+  if (PH != 1) stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane, cprv);
+  if (PH != 2) stage_image_dma<HD>(sK, img, base + os, gs, T, wave, nwaves, lane, cprv);
+  if (PH != 2) stage_image_dma<HD>(sV, img, base + 2 * os, gs, T, wave, nwaves, lane, cprv);
+  if (PH != 1) stage_image_dma<HD>(sdO, img, dobase, os, T, wave, nwaves, lane, cprv);
   // D_t = dO_t . O_t with CPR lanes per row (dO chunk from the staged image, O chunk from global), shuffle-reduced.
   // The O chunks and the log-sum-exps are fetched into registers BEFORE the wait on the staging DMAs, so the two global
   // round trips of a workgroup's prologue overlap instead of following each other (up to PF slots per thread; longer
   // sequences take the plain loop).
   constexpr int CPR = AT<HD>::CPR, PF = 4;
   const int total = Tp * CPR;
-  const bool pf = total <= PF * (int)blockDim.x;
+  const bool pf = PH == 0 && total <= PF * (int)blockDim.x;
   bf16x8 o_pf[PF];
   float l_pf[PF];
   if (pf) {
@@ -322,10 +333,10 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (hdv < HD) {
-    zero_pad_chunks<HD>(sQ, Tp, cprv);
-    zero_pad_chunks<HD>(sK, Tp, cprv);
-    zero_pad_chunks<HD>(sV, Tp, cprv);
-    zero_pad_chunks<HD>(sdO, Tp, cprv);
+    if (PH != 1) zero_pad_chunks<HD>(sQ, Tp, cprv);
+    if (PH != 2) zero_pad_chunks<HD>(sK, Tp, cprv);
+    if (PH != 2) zero_pad_chunks<HD>(sV, Tp, cprv);
+    if (PH != 1) zero_pad_chunks<HD>(sdO, Tp, cprv);
   }
   __syncthreads();
   if (pf) {
@@ -352,7 +363,7 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
       const int t = idx / CPR, cc = idx - t * CPR;
       float D = 0.f;
       if (idx < total && t < T && cc < cprv) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(sdO + t * AT<HD>::RS + cc * 16);
+        const bf16x8 a = PH == 1 ? *reinterpret_cast<const bf16x8*>(dobase + t * os + cc * 8) : *reinterpret_cast<const bf16x8*>(sdO + t * AT<HD>::RS + cc * 16);
         const bf16x8 o = *reinterpret_cast<const bf16x8*>(obase + t * os + cc * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) D = fmaf((float)a[e], (float)o[e], D);
@@ -374,12 +385,13 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
 #ifdef MAE_DBG_ATT_NO_A
   if (T < 0)
 #endif
+  if (PH != 2)
   for (int qt = wave; qt < nt16; qt += nwaves) {
     bf16x8 qf[AT<HD>::NKS], dof[AT<HD>::NKS];
 #pragma unroll
     for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
-      qf[ks] = rowfrag<HD>(sQ, qt * 16, ks, lane);
-      dof[ks] = rowfrag<HD>(sdO, qt * 16, ks, lane);
+      qf[ks] = PH == 1 ? rowfrag_global<HD>(base, gs, qt * 16, ks, lane, T) : rowfrag<HD>(sQ, qt * 16, ks, lane);
+      dof[ks] = PH == 1 ? rowfrag_global<HD>(dobase, os, qt * 16, ks, lane, T) : rowfrag<HD>(sdO, qt * 16, ks, lane);
     }
     const float li = sLse[qt * 16 + i], Di = sD[qt * 16 + i];
     f32x4 dq[AT<HD>::NDT];
@@ -427,12 +439,13 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
 #ifdef MAE_DBG_ATT_NO_B
   if (T < 0)
 #endif
+  if (PH != 1)
   for (int jt = wave; jt < nt16; jt += nwaves) {
     bf16x8 kf[AT<HD>::NKS], vf[AT<HD>::NKS];
 #pragma unroll
     for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
-      kf[ks] = rowfrag<HD>(sK, jt * 16, ks, lane);
-      vf[ks] = rowfrag<HD>(sV, jt * 16, ks, lane);
+      kf[ks] = PH == 2 ? rowfrag_global<HD>(base + os, gs, jt * 16, ks, lane, T) : rowfrag<HD>(sK, jt * 16, ks, lane);
+      vf[ks] = PH == 2 ? rowfrag_global<HD>(base + 2 * os, gs, jt * 16, ks, lane, T) : rowfrag<HD>(sV, jt * 16, ks, lane);
     }
     f32x4 dk[AT<HD>::NDT], dv[AT<HD>::NDT];
 #pragma unroll
@@ -519,6 +532,21 @@ static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, 
   MAE_LAUNCH_CHECK();
   return 0;
 }
+// long sequences: the backward pass as two launches staging two images each (PH = 1: dQ, PH = 2: dK / dV)
+template <int HD>
+static int launch_attn_bwd_split(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int Tp, int H, int hdv, size_t lds,
+                                 float scale, bf16* d_qkv, hipStream_t s) {
+  const int threads = 64 * attn_waves(T, BwdCap<0>::v);
+  auto k1 = attn_bwd_mfma_kernel<HD, 0, 1>;
+  auto k2 = attn_bwd_mfma_kernel<HD, 0, 2>;
+  MAE_HIP(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MAE_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k1, dim3((unsigned)B * H), dim3(threads), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv, 0, 0, hdv, attn_remap());
+  MAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k2, dim3((unsigned)B * H), dim3(threads), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv, 0, 0, hdv, attn_remap());
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
 #define ATTN_DISPATCH(FN, BIG, ...)                                         \
   switch (hdt * 100 + (Tp >> 5)) {                                          \
     case 6401: return FN<64, 1>(__VA_ARGS__);                               \
@@ -545,9 +573,15 @@ int mfma_attention_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, cons
                        bf16* d_qkv, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)d_qkv) & 15)) return MFMA_UNSUPPORTED;
   const int Tp = (int)round_up(T, 32), hdt = hd == 24 ? 32 : hd;
-  const size_t lds = (size_t)4 * round_up((int64_t)Tp * (hdt * 2 + 32), 1024) + (size_t)2 * Tp * 4;
-  if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
+  const size_t img = (size_t)round_up((int64_t)Tp * (hdt * 2 + 32), 1024);
+  const size_t lds = 4 * img + (size_t)2 * Tp * 4;
   const float scale = 1.0f / sqrtf((float)hd);
+  if (lds > 160 * 1024) {
+    const size_t lds2 = 2 * img + (size_t)2 * Tp * 4;
+    if (lds2 > 160 * 1024 || hd != hdt) return MFMA_UNSUPPORTED;
+    return hdt == 64 ? launch_attn_bwd_split<64>(qkv, out, d_out, lse, B, T, Tp, H, hd, lds2, scale, d_qkv, s)
+                     : launch_attn_bwd_split<32>(qkv, out, d_out, lse, B, T, Tp, H, hd, lds2, scale, d_qkv, s);
+  }
   ATTN_DISPATCH(launch_attn_bwd, 0, qkv, out, d_out, lse, B, T, Tp, H, hd, lds, scale, d_qkv, s)
 }
 
