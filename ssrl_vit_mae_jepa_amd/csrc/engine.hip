@@ -538,8 +538,7 @@ static int backward_decoder_impl(const Ctx& c, const Plan& pl, const JepaSeq* jp
   MAE_TRY(dgrad(c, c.buf<>(pl.dpred), e->i_pred_w, pl.Mp, e->PO, e->Dd, MAE_EPI_NONE, c.buf<>(pl.d_decn), nullptr));
   // decoder_norm over the masked rows only: every other row of the residual gradient is zero
   MAE_TRY(await_side(e, DEP_DRESC, s));
-  MAE_HIP(hipMemsetAsync(dres, 0, (size_t)pl.Md * e->Dd * 4, s));
-  MAE_HIP(hipMemsetAsync(dres_c, 0, (size_t)pl.Md * e->Dd * c.as, s));
+  RUN(TK_DATA, 0, (pl.Md - pl.Mp) * e->Dd * (4 + c.as), launch_zero_unpredicted_rows(jp ? nullptr : c.buf<int32_t>(pl.inv), pl.Md, pl.dec_T, pl.m, e->Dd, c.act, dres, dres_c, s));
   RUN(TK_LN_BWD, 0, pl.Mp * e->Dd * (12 + 2 * c.as), launch_layernorm_bwd(c.buf<>(pl.d_decn), c.act, c.buf<float>(pl.dec_x[e->dd]), c.buf<int32_t>(pl.pred_rows), c.P(e->i_dn_w), c.buf<float>(pl.dec_mean), c.buf<float>(pl.dec_rstd), pl.Mp, e->Dd, 0, dres, dres_c, c.Gp(e->i_dn_w), c.Gp(e->i_dn_b), ln_slot(c, pl), s, &e->ln_tab));
   for (int i = e->dd - 1; i >= 0; --i)
     MAE_TRY(block_backward(c, pl, e->dec[i], pl.dec[i], pl.Md, e->Dd, e->Hd, pl.dec_B, pl.dec_T, pl.dec_x[i]));

@@ -82,9 +82,24 @@ template <class V> __device__ __forceinline__ void stream_store(V v, V* p) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #endif
 }
+// Stores that cover only PART of a 128-byte line: the 32-column group a wave shares with its neighbour (a third of every bf16 output) and
+// fp32 rows, whose two 16-byte halves per lane go out in two instructions.  Non-temporal partial lines are not merged in L2 and reach HBM
+// piece by piece: PMC WRITE_SIZE shows +10-11 % on every bf16 launch and +25-33 % on the fp32 ones, 2.1 GB per step; with ordinary stores
+// for those pieces (-DMAE_NT3_PART_STORE=1) the counter equals the algorithmic bytes exactly (step 98.6 -> 96.5 GB) but the step is 0.07-0.13 ms
+// SLOWER (linear_nt 10.12 -> 10.22 ms, 2 x A/B on one box: the dirty lines now wait in L2 for their other half).  Time wins: nt everywhere.
+#ifndef MAE_NT3_PART_STORE
+#define MAE_NT3_PART_STORE 0
+#endif
+template <class V> __device__ __forceinline__ void part_store(V v, V* p) {
+#if MAE_NT3_PART_STORE == 1
+  *p = v;
+#else
+  stream_store(v, p);
+#endif
+}
 __device__ __forceinline__ void st8(float* p, const f32x4& a, const f32x4& b) {
-  stream_store(a, reinterpret_cast<f32x4*>(p));
-  stream_store(b, reinterpret_cast<f32x4*>(p + 4));
+  part_store(a, reinterpret_cast<f32x4*>(p));
+  part_store(b, reinterpret_cast<f32x4*>(p + 4));
 }
 __device__ __forceinline__ bf16x8 pk8(const f32x4& a, const f32x4& b) {
   return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
@@ -334,7 +349,7 @@ __global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __res
           if (r2 < M) stream_store(lo8 ? R : Bv, reinterpret_cast<bf16x8*>(dst + r2 * N + col));
         };
         auto store_single = [&](TO* __restrict__ dst, const bf16x8& v, int j) {
-          if (m < M) stream_store(v, reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j));
+          if (m < M) part_store(v, reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j));
         };
         if (NJ == 2) {
           store_rows(out, pa, 0);

@@ -379,6 +379,36 @@ int launch_add_into(const float* src, void* dst, int dst_dt, int64_t n, hipStrea
   return 0;
 }
 
+// The backward pass of the decoder starts from a residual gradient that is zero on every row the prediction head never saw: the
+// visible rows (inv[row] >= 0, MAE) or the first T - m rows of every sequence (inv == nullptr, I-JEPA's predictor).  Only those
+// rows are cleared here (a quarter of the rows at mask ratio 0.75); the decoder_norm backward then writes the others.
+template <class T>
+__global__ void __launch_bounds__(256) zero_unpredicted_rows_kernel(const int32_t* __restrict__ inv, int64_t rows, int Tseq, int m, int D4,
+                                                                    float* __restrict__ dres, T* __restrict__ dres_c) {
+  const int lanes = D4 <= 64 ? 64 : 128;   // threads per row: one float4 each, two passes at most for D <= 1024
+  const int rpb = 256 / lanes, sub = threadIdx.x / lanes, l = threadIdx.x % lanes;
+  for (int64_t row = (int64_t)blockIdx.x * rpb + sub; row < rows; row += (int64_t)gridDim.x * rpb) {
+    const bool clear = inv ? inv[row] >= 0 : (int)(row % Tseq) < Tseq - m;
+    if (!clear) continue;
+    for (int c = l; c < D4; c += lanes) {
+      store4(dres + row * (int64_t)D4 * 4 + c * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+      store4(dres_c + row * (int64_t)D4 * 4 + c * 4, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  }
+}
+
+int launch_zero_unpredicted_rows(const int32_t* inv, int64_t rows, int Tseq, int m, int D, int act, float* dres, void* dres_c, hipStream_t s) {
+  MAE_REQUIRE(dres && dres_c && rows > 0 && D % 4 == 0 && Tseq > 0 && m >= 0 && m <= Tseq, "zero_unpredicted_rows: bad arguments");
+  const int rpb = D / 4 <= 64 ? 4 : 2;
+  const int grid = (int)std::min<int64_t>(cdiv(rows, rpb), 8192);
+  if (act == MAE_BF16)
+    hipLaunchKernelGGL(zero_unpredicted_rows_kernel<bf16>, dim3(grid), dim3(256), 0, s, inv, rows, Tseq, m, D / 4, dres, reinterpret_cast<bf16*>(dres_c));
+  else
+    hipLaunchKernelGGL(zero_unpredicted_rows_kernel<float>, dim3(grid), dim3(256), 0, s, inv, rows, Tseq, m, D / 4, dres, reinterpret_cast<float*>(dres_c));
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace mae
 
 extern "C" int mae_patchify_gather(const void* images, int32_t image_dtype, const int64_t* idx_mask, int32_t batch, int32_t in_chans,

@@ -30,6 +30,7 @@ int launch_visible_grad_split(const float* dx, const int32_t* tok, int64_t rows,
 int launch_decoder_assemble(const void* xdec, int dt, const int32_t* inv, const float* mask_token, const float* pos,
                             int B, int k, int L, int Dd, float* out, hipStream_t s);
 // d_xdec[b*k+j] (dt) = dx[b][keep[b][j]];  d_mask_token[Dd] = sum over rows with inv < 0.  partial: >= 512*Dd floats
+int launch_zero_unpredicted_rows(const int32_t* inv, int64_t rows, int Tseq, int m, int D, int act, float* dres, void* dres_c, hipStream_t s);
 int launch_decoder_assemble_bwd(const float* dx, const int32_t* inv, const int32_t* keep, int B, int k, int L, int Dd,
                                 int dt, void* d_xdec, float* d_mask_token, float* partial, hipStream_t s);
 // target (B*m, P) fp32 in (py, px, c) order for patch max(mask[b][j]-1, 0)
