@@ -452,7 +452,11 @@ __global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __res
     // may stay in flight too
     const bool stores = tile > 0 && prev_full;
     for (int k = 1; k < nk; ++k) {
+#ifdef MAE_DBG_NT3_LOOSE   // TIMING PROBE, WRONG VALUES: the epilogue's stores may stay in flight for LOOSE steps instead of one
+      if (k <= MAE_DBG_NT3_LOOSE && stores) { NT3_STEP_TOP(NAF + E) } else { NT3_STEP_TOP(NAF) }
+#else
       if (k == 1 && stores) { NT3_STEP_TOP(NAF + E) } else { NT3_STEP_TOP(NAF) }
+#endif
       NT3_PHASE1()
       NT3_PHASE2()
     }
