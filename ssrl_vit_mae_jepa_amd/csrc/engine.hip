@@ -702,7 +702,7 @@ static int refresh_transposed(mae_engine* e, const float* params, void* wcache, 
     const int rows = (int)pi.shape[0], cols = (int)(pi.numel / pi.shape[0]);
     const int i = tab.n++;
     tab.src_off[i] = pi.offset; tab.dst_off[i] = pi.t_off; tab.rows[i] = rows; tab.cols[i] = cols;
-    tab.tile_begin[i + 1] = tab.tile_begin[i] + (int)(cdiv(rows, 32) * cdiv(cols, 32));
+    tab.tile_begin[i + 1] = tab.tile_begin[i] + (int)(cdiv(rows, TransposeTable::TILE) * cdiv(cols, TransposeTable::TILE));
     if (tab.n == TransposeTable::MAX) { MAE_TRY(flush()); tab.tile_begin[0] = 0; }
   }
   return flush();

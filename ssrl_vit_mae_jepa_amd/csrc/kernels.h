@@ -83,7 +83,7 @@ int launch_f32_to_bf16(const float* src, bf16* dst, int64_t n, hipStream_t s);
 int launch_transpose_to_bf16(const float* src, bf16* dst, int rows, int cols, hipStream_t s);
 // the same for a whole list of matrices living in one arena (one launch); passed by value as a kernel argument
 struct TransposeTable {
-  static constexpr int MAX = 64;
+  static constexpr int MAX = 64, TILE = 64;   // matrices per launch, tile edge
   int n = 0, total_tiles = 0;
   int64_t src_off[MAX], dst_off[MAX];
   int rows[MAX], cols[MAX], tile_begin[MAX + 1];
