@@ -140,14 +140,23 @@ __device__ __forceinline__ int att_block(int remap) {
 template <int HD> struct FwdCap { static constexpr int v = 512; };  // (10 waves for the 145-token decoder forward measured 12 % slower than 5 waves x 2 passes)
 template <int NCH> struct BwdCap { static constexpr int v = NCH == 0 ? 1024 : 512; };
 
-template <int HD, int NCH>
+// row fragment of the caller's own tile straight from global memory (rows past T clamp to T - 1: masked or multiplied by zero downstream)
+template <int HD>
+__device__ __forceinline__ bf16x8 rowfrag_global(const bf16* g, int64_t gs, int row0, int ks, int lane, int T) {
+  int row = row0 + (lane & 15);
+  row = row < T ? row : T - 1;
+  return *reinterpret_cast<const bf16x8*>(g + row * gs + ks * 32 + 8 * (lane >> 4));
+}
+
+// FQ: the query tile's fragments come straight from global memory and only K and V are staged (sequences whose three images exceed the LDS)
+template <int HD, int NCH, bool FQ = false>
 __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, int T, int Tp, int H, float scale,
                                                             bf16* __restrict__ out, float* __restrict__ lse, int stagger, int gen1, int hdv, int remap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   first_generation_stagger(stagger, gen1);
   const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
-  char* sK = sQ + img;
+  char* sK = FQ ? smem : sQ + img;
   char* sV = sK + img;
   const int vb = att_block(remap);
   const int b = vb / H, h = vb - b * H;
@@ -156,12 +165,12 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
   const bf16* base = qkv + (int64_t)b * T * gs + h * hdv;
   const int lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane, cprv);
+  if (!FQ) stage_image_dma<HD>(sQ, img, base, gs, T, wave, nwaves, lane, cprv);
   stage_image_dma<HD>(sK, img, base + (int64_t)H * hdv, gs, T, wave, nwaves, lane, cprv);
   stage_image_dma<HD>(sV, img, base + 2ll * H * hdv, gs, T, wave, nwaves, lane, cprv);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (hdv < HD) {
-    zero_pad_chunks<HD>(sQ, Tp, cprv);
+    if (!FQ) zero_pad_chunks<HD>(sQ, Tp, cprv);
     zero_pad_chunks<HD>(sK, Tp, cprv);
     zero_pad_chunks<HD>(sV, Tp, cprv);
   }
@@ -172,7 +181,7 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
   for (int qt = wave; qt < nq; qt += nwaves) {
     bf16x8 qf[AT<HD>::NKS];
 #pragma unroll
-    for (int ks = 0; ks < AT<HD>::NKS; ++ks) qf[ks] = rowfrag<HD>(sQ, qt * 16, ks, lane);
+    for (int ks = 0; ks < AT<HD>::NKS; ++ks) qf[ks] = FQ ? rowfrag_global<HD>(base, gs, qt * 16, ks, lane, T) : rowfrag<HD>(sQ, qt * 16, ks, lane);
     f32x4 oacc[AT<HD>::NDT];
 #pragma unroll
     for (int dt = 0; dt < AT<HD>::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -276,14 +285,6 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
 // PH = 0: both phases from four staged images (Q, K, V, dO).  Sequences whose four images do not fit the LDS run as TWO launches that stage
 // two images each and take their own 16-token tile's fragments straight from global memory: PH = 1 (dQ: K, V staged) and PH = 2 (dK / dV:
 // Q, dO staged).  Same arithmetic in the same order as PH = 0.
-// row fragment of the caller's own tile straight from global memory (rows past T clamp to T - 1: masked or multiplied by zero downstream)
-template <int HD>
-__device__ __forceinline__ bf16x8 rowfrag_global(const bf16* g, int64_t gs, int row0, int ks, int lane, int T) {
-  int row = row0 + (lane & 15);
-  row = row < T ? row : T - 1;
-  return *reinterpret_cast<const bf16x8*>(g + row * gs + ks * 32 + 8 * (lane >> 4));
-}
-
 template <int HD, int NCH, int PH = 0>
 __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ d_out, const float* __restrict__ lse, int T,
@@ -560,12 +561,25 @@ static int launch_attn_bwd_split(const bf16* qkv, const bf16* out, const bf16* d
     default: return hdt == 64 ? FN<64, 0>(__VA_ARGS__) : FN<32, 0>(__VA_ARGS__); \
   }
 
+template <int HD>
+static int launch_attn_fwd_fq(const bf16* qkv, int B, int T, int Tp, int H, int hdv, size_t lds, float scale, bf16* out, float* lse, hipStream_t s) {
+  auto kern = attn_fwd_mfma_kernel<HD, 0, true>;
+  MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, FwdCap<HD>::v)), lds, s, qkv, T, Tp, H, scale, out, lse, 0, 0, hdv, attn_remap());
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int mfma_attention_fwd(const bf16* qkv, int B, int T, int H, int hd, bf16* out, float* lse, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return MFMA_UNSUPPORTED;
   const int Tp = (int)round_up(T, 32), hdt = hd == 24 ? 32 : hd;
-  const size_t lds = (size_t)3 * round_up((int64_t)Tp * (hdt * 2 + 32), 1024);
-  if (lds > 160 * 1024) return MFMA_UNSUPPORTED;
+  const size_t img = (size_t)round_up((int64_t)Tp * (hdt * 2 + 32), 1024);
+  const size_t lds = 3 * img;
   const float scale = 1.0f / sqrtf((float)hd);
+  if (lds > 160 * 1024) {   // three images do not fit: K and V only, query fragments from global memory
+    if (2 * img > 160 * 1024 || hd != hdt) return MFMA_UNSUPPORTED;
+    return hdt == 64 ? launch_attn_fwd_fq<64>(qkv, B, T, Tp, H, hd, 2 * img, scale, out, lse, s) : launch_attn_fwd_fq<32>(qkv, B, T, Tp, H, hd, 2 * img, scale, out, lse, s);
+  }
   ATTN_DISPATCH(launch_attn_fwd, 5, qkv, B, T, Tp, H, hd, lds, scale, out, lse, s)
 }
 

@@ -324,7 +324,8 @@ def _attn_ref(qkv, B, T, H, hd):
 
 
 @pytest.mark.parametrize("B,T,H,hd", [(3, 36, 6, 24), (2, 145, 6, 32), (5, 36, 6, 64), (2, 145, 8, 64), (1, 17, 2, 24), (2, 72, 6, 64), (1, 300, 2, 32), (4, 1, 2, 32),
-                                      (2, 257, 4, 64), (1, 304, 2, 64), (1, 480, 2, 32)])  # the last three: backward as two launches (four images exceed the LDS)
+                                      (2, 257, 4, 64), (1, 304, 2, 64), (1, 480, 2, 32),   # backward as two launches (four images exceed the LDS)
+                                      (1, 500, 2, 64), (1, 700, 2, 32), (1, 600, 1, 64)])  # forward with Q from global memory (three images exceed it); beyond that the block-streamed fallback
 @pytest.mark.parametrize("dt", [F32, BF16])
 def test_attention_fwd_bwd(dev, B, T, H, hd, dt):
     g = G(T * 3 + hd)
