@@ -351,9 +351,12 @@ __global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __res
         auto store_single = [&](TO* __restrict__ dst, const bf16x8& v, int j) {
           if (m < M) part_store(v, reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j));
         };
-        if (NJ == 2) {
-          store_rows(out, pa, 0);
-          if (TWO) store_rows(out2, pb, 0);
+        if (NJ % 2 == 0) {   // the wave's columns are whole 128-byte lines (128- and 256-wide tiles)
+#pragma unroll
+          for (int ja = 0; ja < NJ; ja += 2) {
+            store_rows(out, pa, ja);
+            if (TWO) store_rows(out2, pb, TWO ? ja : 0);
+          }
         } else if (wn == 0) {
           store_rows(out, pa, 0); store_single(out, pa[NJ - 1], NJ - 1);
           if (TWO) { store_rows(out2, pb, 0); store_single(out2, pb[TWO ? NJ - 1 : 0], NJ - 1); }
@@ -522,6 +525,12 @@ template <int MODE, class TO>
 static int launch_nt3_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, const Epi& e, hipStream_t s) {
   const char* var = getenv("MAE_GEMM_NT");   // A/B: "v3w2" = two 4-wave workgroups per CU on 128-row tiles
   const bool w2 = var && strstr(var, "w2") != nullptr;
+  // Widths that are multiples of 256 take 192 x 256 tiles -- the 256 x 192 tile transposed: same staged bytes per flop and the same 24 MFMA tiles per
+  // wave (48 x 128), but a wave then owns 128 columns = two whole 128-byte lines of every output row (no partial-line stores) and a row panel is
+  // shared by N / 256 workgroups instead of N / 192.  gemm_bench: -4 ... -11 % on the fc1 / fc2-dgrad / 512- and 1024-wide launches, bit-identical;
+  // in the step: default -0.08 ms, ViT-B/16 -0.5 ms, ViT-L/14 -3.7 ms.  MAE_NT_N256=0 keeps the 192-wide tiles (A/B).
+  static const int n256 = [] { const char* v = getenv("MAE_NT_N256"); return v ? atoi(v) : 1; }();
+  if (n256 && N % 256 == 0 && !w2) return launch_nt3<MODE, TO, 8, 3, 4>(A, W, M, N, K, e, s);
   if (N % 192 == 0) {
     if (w2) return launch_nt3<MODE, TO, 6, 4, 2>(A, W, M, N, K, e, s);
     if (prefer_bm192_3(M, N)) return launch_nt3<MODE, TO, 6, 3, 4>(A, W, M, N, K, e, s);
