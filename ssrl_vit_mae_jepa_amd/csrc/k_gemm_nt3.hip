@@ -531,6 +531,7 @@ static int launch_nt3_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, 
   // in the step: default -0.08 ms, ViT-B/16 -0.5 ms, ViT-L/14 -3.7 ms.  MAE_NT_N256=0 keeps the 192-wide tiles (A/B).
   static const int n256 = [] { const char* v = getenv("MAE_NT_N256"); return v ? atoi(v) : 1; }();
   if (n256 && N % 256 == 0 && !w2) return launch_nt3<MODE, TO, 8, 3, 4>(A, W, M, N, K, e, s);
+  // (128 x 384 tiles -- wave tile 32 x 192, three whole lines per row, for 384 / 1152 -- stage 14 % more bytes per flop: +1.0 ms per step, not kept)
   if (N % 192 == 0) {
     if (w2) return launch_nt3<MODE, TO, 6, 4, 2>(A, W, M, N, K, e, s);
     if (prefer_bm192_3(M, N)) return launch_nt3<MODE, TO, 6, 3, 4>(A, W, M, N, K, e, s);
