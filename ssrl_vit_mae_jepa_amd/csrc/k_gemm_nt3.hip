@@ -42,11 +42,12 @@ constexpr int BK3 = 64;
 // (the epilogue reads the bias from L2).
 template <int NI, int MI, int WM>
 struct Geo3 {
-  static constexpr int NWV = 2 * WM;                                  // waves per workgroup
-  static constexpr int BN = 32 * NI, BM = 16 * MI * WM;
+  static constexpr int WN = WM == 8 ? 1 : 2;                          // waves along N (WM = 8: eight waves along M, each owning whole rows of the tile)
+  static constexpr int NWV = WN * WM;                                 // waves per workgroup
+  static constexpr int BN = 16 * NI * WN, BM = 16 * MI * WM;
   static constexpr int ASTG = BM * BK3 * 2, WSTG = BN * BK3 * 2;      // one K-step of activation rows / of weight rows, 128 B per row
-  static constexpr int CAP = WM == 4 ? 160 * 1024 : 80 * 1024;
-  static constexpr bool STRIP = WM == 4;                              // bias strips of two tiles in LDS
+  static constexpr int CAP = NWV == 8 ? 160 * 1024 : 80 * 1024;
+  static constexpr bool STRIP = NWV == 8;                              // bias strips of two tiles in LDS
   static constexpr int TAIL = STRIP ? 2 * BN * 4 : 0;
   static constexpr int SW = 2;                                        // weight ring: L2 hits, one step ahead
   static constexpr int SA_ = (CAP - TAIL - SW * WSTG) / ASTG;
@@ -166,7 +167,7 @@ struct Spread {
 }  // namespace
 
 template <int MODE, class TO, bool HAS_BIAS, int NI, int MI, int WM>
-__global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M, int N, int K,
+__global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int64_t M, int N, int K,
                                                                const float* __restrict__ bias, const void* __restrict__ aux, TO* __restrict__ out,
                                                                TO* __restrict__ out2, int tiles_m, int tiles_n, int a_nt) {
   using G_ = Geo3<NI, MI, WM>;
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(128 * WM, 2) gemm_nt3_kernel(const bf16* __res
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / G_::WN, wn = wave % G_::WN;
   constexpr int WROWS = 16 * MI;
   const int fr = lane & 15, fq = lane >> 4;
   const int G = gridDim.x, T = tiles_m * tiles_n;
@@ -492,7 +493,7 @@ static int launch_nt3(const bf16* A, const bf16* W, int64_t M, int N, int K, con
   const int64_t T = cdiv(M, G_::BM) * (N / G_::BN);
   MAE_REQUIRE(T < (1ll << 30), "gemm: too many tiles");
   const int tiles_m = (int)cdiv(M, G_::BM), tiles_n = N / G_::BN;
-  const int grid = (int)std::min<int64_t>(T, (int64_t)num_cus() * (WM == 4 ? 1 : 2));  // persistent: one 8-wave or two 4-wave workgroups per CU
+  const int grid = (int)std::min<int64_t>(T, (int64_t)num_cus() * (G_::NWV == 8 ? 1 : 2));  // persistent: one 8-wave or two 4-wave workgroups per CU
   // activation rows that a single workgroup reads (tiles_n == 1: the 192-wide decoder outputs) are streamed with the non-temporal policy:
   // cold, those shapes run 15-21 % faster (profiles/r03_nt3_kloop.txt); panels shared by several tile columns must stay in L2.
   // MAE_NT3_ANT = largest tiles_n that gets the policy (0 = never; A/B)
@@ -501,11 +502,11 @@ static int launch_nt3(const bf16* A, const bf16* W, int64_t M, int N, int K, con
   if (e.bias) {
     auto kern = gemm_nt3_kernel<MODE, TO, true, NI, MI, WM>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n, a_nt);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * G_::NWV), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n, a_nt);
   } else {
     auto kern = gemm_nt3_kernel<MODE, TO, false, NI, MI, WM>;
     MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n, a_nt);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * G_::NWV), G_::LDS, s, A, W, M, N, K, e.bias, e.aux, (TO*)e.out, (TO*)e.out2, tiles_m, tiles_n, a_nt);
   }
   MAE_LAUNCH_CHECK();
   return 0;
@@ -535,6 +536,11 @@ static int launch_nt3_ni(const bf16* A, const bf16* W, int64_t M, int N, int K, 
   if (N % 192 == 0) {
     if (w2) return launch_nt3<MODE, TO, 6, 4, 2>(A, W, M, N, K, e, s);
     if (prefer_bm192_3(M, N)) return launch_nt3<MODE, TO, 6, 3, 4>(A, W, M, N, K, e, s);
+    // bf16 outputs: the 256 x 192 tile with EIGHT waves along M, each owning 32 whole rows (three full lines per row: no partial-line stores; 14 instead
+    // of 10 fragment reads per half-step, which the LDS absorbs).  gemm_bench -1 ... -4 % on the 192- / 576- / 1152-wide launches, K = 4096 1278 -> 1285 TF/s,
+    // step -0.02 ... -0.05 ms; fp32 outputs (two half-row stores per lane) lose 3 % and keep the 4 x 2 layout.  MAE_NT_WN1=0: 4 x 2 everywhere (A/B).
+    static const int wn1 = [] { const char* v = getenv("MAE_NT_WN1"); return v ? atoi(v) : 1; }();
+    if (wn1 && sizeof(TO) == 2) return launch_nt3<MODE, TO, 12, 2, 8>(A, W, M, N, K, e, s);
     return launch_nt3<MODE, TO, 6, 4, 4>(A, W, M, N, K, e, s);
   }
   if (w2) return launch_nt3<MODE, TO, 4, 4, 2>(A, W, M, N, K, e, s);
