@@ -75,18 +75,23 @@ __device__ __forceinline__ void zero_pad_chunks(char* s, int rows, int cprv) {
 }
 
 // operand indexed by token row (row0 + lane&15), elements hd = ks*32 + 8*(lane>>4) .. +7
-template <int HD>
-__device__ __forceinline__ bf16x8 rowfrag(const char* s, int row0, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(s + (row0 + (lane & 15)) * AT<HD>::RS + (ks * 32 + 8 * (lane >> 4)) * 2);
+// CL: the image holds round_up(T, 16) rows instead of the chunk loops' round_up(T, 32); rows past it read the last row (their probability is zero).
+// Only the short unrolled variants trim (a fourth encoder-backward workgroup fits a CU); the clamp costs the long, VALU-bound ones 4-6 %.
+template <int HD, bool CL>
+__device__ __forceinline__ bf16x8 rowfrag(const char* s, int row0, int ks, int lane, int rmax) {
+  const int row = CL ? min(row0 + (lane & 15), rmax) : row0 + (lane & 15);
+  return *reinterpret_cast<const bf16x8*>(s + row * AT<HD>::RS + (ks * 32 + 8 * (lane >> 4)) * 2);
 }
 
 // operand indexed by hd column (c0 + lane&15), elements = tokens j0 + 16h + 4*(lane>>4) + q, (h,q) = element>>2, &3
-template <int HD>
-__device__ __forceinline__ bf16x8 trfrag(const char* s, int j0, int c0, int lane) {
+template <int HD, bool CL>
+__device__ __forceinline__ bf16x8 trfrag(const char* s, int j0, int c0, int lane, int rmax) {
   const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-  const char* a = s + (j0 + 4 * g + q) * AT<HD>::RS + (c0 + 4 * p) * 2;
+  const int r = j0 + 4 * g + q;
+  const char* a = s + (CL ? min(r, rmax) : r) * AT<HD>::RS + (c0 + 4 * p) * 2;
+  const char* a2 = CL ? s + min(r + 16, rmax) * AT<HD>::RS + (c0 + 4 * p) * 2 : a + 16 * AT<HD>::RS;
   const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a + 16 * AT<HD>::RS));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a2));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
@@ -154,7 +159,9 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
                                                             bf16* __restrict__ out, float* __restrict__ lse, int stagger, int gen1, int hdv, int remap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   first_generation_stagger(stagger, gen1);
-  const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
+  constexpr bool CL = NCH >= 1 && NCH <= 3;
+  const int Ti = CL ? (T + 15) & ~15 : Tp, rmax = Ti - 1;   // rows an image holds (Tp = the 32-key chunk padding of the loops)
+  const int img = (Ti * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
   char* sK = FQ ? smem : sQ + img;
   char* sV = sK + img;
@@ -170,9 +177,9 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
   stage_image_dma<HD>(sV, img, base + 2ll * H * hdv, gs, T, wave, nwaves, lane, cprv);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (hdv < HD) {
-    if (!FQ) zero_pad_chunks<HD>(sQ, Tp, cprv);
-    zero_pad_chunks<HD>(sK, Tp, cprv);
-    zero_pad_chunks<HD>(sV, Tp, cprv);
+    if (!FQ) zero_pad_chunks<HD>(sQ, Ti, cprv);
+    zero_pad_chunks<HD>(sK, Ti, cprv);
+    zero_pad_chunks<HD>(sV, Ti, cprv);
   }
   __syncthreads();
   const int g = lane >> 4, i = lane & 15;
@@ -181,7 +188,7 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
   for (int qt = wave; qt < nq; qt += nwaves) {
     bf16x8 qf[AT<HD>::NKS];
 #pragma unroll
-    for (int ks = 0; ks < AT<HD>::NKS; ++ks) qf[ks] = FQ ? rowfrag_global<HD>(base, gs, qt * 16, ks, lane, T) : rowfrag<HD>(sQ, qt * 16, ks, lane);
+    for (int ks = 0; ks < AT<HD>::NKS; ++ks) qf[ks] = FQ ? rowfrag_global<HD>(base, gs, qt * 16, ks, lane, T) : rowfrag<HD, CL>(sQ, qt * 16, ks, lane, rmax);
     f32x4 oacc[AT<HD>::NDT];
 #pragma unroll
     for (int dt = 0; dt < AT<HD>::NDT; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -197,8 +204,8 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
         s0[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[c] = s0[c];
 #pragma unroll
         for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
-          s0[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32, ks, lane), qf[ks], s0[c], 0, 0, 0);
-          s1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32 + 16, ks, lane), qf[ks], s1[c], 0, 0, 0);
+          s0[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sK, c * 32, ks, lane, rmax), qf[ks], s0[c], 0, 0, 0);
+          s1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sK, c * 32 + 16, ks, lane, rmax), qf[ks], s1[c], 0, 0, 0);
         }
       }
       {  // only the last chunk holds keys past T
@@ -226,15 +233,15 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
         const bf16x8 pf = pack8(s0[c], s1[c]);
 #pragma unroll
         for (int dt = 0; dt < AT<HD>::NDT; ++dt)
-          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sV, c * 32, dt * 16, lane), pf, oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD, CL>(sV, c * 32, dt * 16, lane, rmax), pf, oacc[dt], 0, 0, 0);
       }
     } else {
     for (int c = 0; c < nchunks; ++c) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32, ks, lane), qf[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32 + 16, ks, lane), qf[ks], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sK, c * 32, ks, lane, rmax), qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sK, c * 32 + 16, ks, lane, rmax), qf[ks], s1, 0, 0, 0);
       }
       // lane: query i, keys j = c*32 + 4g + r (s0) and c*32 + 16 + 4g + r (s1)
       const int j0 = c * 32 + 4 * g;
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(FwdCap<HD>::v) attn_fwd_mfma_kernel(const bf16
 #pragma unroll
       for (int dt = 0; dt < AT<HD>::NDT; ++dt) {
         oacc[dt] *= alpha;
-        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sV, c * 32, dt * 16, lane), pf, oacc[dt], 0, 0, 0);
+        oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD, CL>(sV, c * 32, dt * 16, lane, rmax), pf, oacc[dt], 0, 0, 0);
       }
       m = mn;
     }
@@ -291,7 +298,9 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
                                                             int Tp, int H, float scale, bf16* __restrict__ d_qkv, int stagger, int gen1, int hdv, int remap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   first_generation_stagger(stagger, gen1);
-  const int img = (Tp * AT<HD>::RS + 1023) & ~1023;
+  constexpr bool CL = NCH >= 1 && NCH <= 3;
+  const int Ti = CL ? (T + 15) & ~15 : Tp, rmax = Ti - 1;   // rows an image holds (Tp = the 32-key chunk padding of the loops)
+  const int img = (Ti * AT<HD>::RS + 1023) & ~1023;
   char* sQ = smem;
   char* sK = PH == 1 ? smem : sQ + img;
   char* sV = sK + img;
@@ -316,9 +325,19 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   // The O chunks and the log-sum-exps are fetched into registers BEFORE the wait on the staging DMAs, so the two global
   // round trips of a workgroup's prologue overlap instead of following each other (up to PF slots per thread; longer
   // sequences take the plain loop).
+  // DPM (the unrolled lengths): D_t is not formed from dO_t . O_t at all but as sum_j P_tj dP_tj inside phase A, where a wave holds every
+  // P and dP of its 16 queries in registers (the two sums are the same number: O = P V, dP = dO V^T) -- the O rows (a ninth of the
+  // kernel's bytes) are never read, and the prologue shrinks to the log-sum-exps.
+  constexpr bool DPM = NCH > 0 && PH == 0;
   constexpr int CPR = AT<HD>::CPR, PF = 4;
   const int total = Tp * CPR;
-  const bool pf = PH == 0 && total <= PF * (int)blockDim.x;
+  const bool pf = !DPM && PH == 0 && total <= PF * (int)blockDim.x;
+  if (DPM) {
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+      sLse[t] = t < T ? lse[((int64_t)b * H + h) * T + t] * kLog2e : 1e30f;
+      sD[t] = 0.f;
+    }
+  }
   bf16x8 o_pf[PF];
   float l_pf[PF];
   if (pf) {
@@ -334,10 +353,10 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (hdv < HD) {
-    if (PH != 1) zero_pad_chunks<HD>(sQ, Tp, cprv);
-    if (PH != 2) zero_pad_chunks<HD>(sK, Tp, cprv);
-    if (PH != 2) zero_pad_chunks<HD>(sV, Tp, cprv);
-    if (PH != 1) zero_pad_chunks<HD>(sdO, Tp, cprv);
+    if (PH != 1) zero_pad_chunks<HD>(sQ, Ti, cprv);
+    if (PH != 2) zero_pad_chunks<HD>(sK, Ti, cprv);
+    if (PH != 2) zero_pad_chunks<HD>(sV, Ti, cprv);
+    if (PH != 1) zero_pad_chunks<HD>(sdO, Ti, cprv);
   }
   __syncthreads();
   if (pf) {
@@ -358,7 +377,7 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
         sLse[t] = t < T ? l_pf[it] * kLog2e : 1e30f;
       }
     }
-  } else {
+  } else if (!DPM) {
     for (int base = 0; base < total; base += blockDim.x) {
       const int idx = base + threadIdx.x;
       const int t = idx / CPR, cc = idx - t * CPR;
@@ -377,7 +396,7 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
       }
     }
   }
-  __syncthreads();
+  if (!DPM) __syncthreads();
   const int g = lane >> 4, i = lane & 15;
   const float sl2 = scale * kLog2e;
   const int nt16 = (T + 15) >> 4, nchunks = NCH > 0 ? NCH : (Tp >> 5);
@@ -391,22 +410,70 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
     bf16x8 qf[AT<HD>::NKS], dof[AT<HD>::NKS];
 #pragma unroll
     for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
-      qf[ks] = PH == 1 ? rowfrag_global<HD>(base, gs, qt * 16, ks, lane, T) : rowfrag<HD>(sQ, qt * 16, ks, lane);
-      dof[ks] = PH == 1 ? rowfrag_global<HD>(dobase, os, qt * 16, ks, lane, T) : rowfrag<HD>(sdO, qt * 16, ks, lane);
+      qf[ks] = PH == 1 ? rowfrag_global<HD>(base, gs, qt * 16, ks, lane, T) : rowfrag<HD, CL>(sQ, qt * 16, ks, lane, rmax);
+      dof[ks] = PH == 1 ? rowfrag_global<HD>(dobase, os, qt * 16, ks, lane, T) : rowfrag<HD, CL>(sdO, qt * 16, ks, lane, rmax);
     }
-    const float li = sLse[qt * 16 + i], Di = sD[qt * 16 + i];
+    const float li = sLse[qt * 16 + i];
     f32x4 dq[AT<HD>::NDT];
 #pragma unroll
     for (int dt = 0; dt < AT<HD>::NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (DPM) {
+      constexpr int NC = NCH > 0 ? NCH : 1;
+      f32x4 P0[NC], P1[NC], G0[NC], G1[NC];   // probabilities and dP = dO V^T of the tile's 16 queries against every key
+      float dpart = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        G0[c] = s0; G1[c] = s0;
+#pragma unroll
+        for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sK, c * 32, ks, lane, rmax), qf[ks], s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sK, c * 32 + 16, ks, lane, rmax), qf[ks], s1, 0, 0, 0);
+          G0[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sV, c * 32, ks, lane, rmax), dof[ks], G0[c], 0, 0, 0);
+          G1[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sV, c * 32 + 16, ks, lane, rmax), dof[ks], G1[c], 0, 0, 0);
+        }
+        if (c == NC - 1) {  // only the last chunk holds keys past T
+          const int j0 = c * 32 + 4 * g;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (j0 + r >= T) s0[r] = -INFINITY;
+            if (j0 + 16 + r >= T) s1[r] = -INFINITY;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          P0[c][r] = __builtin_amdgcn_exp2f(fmaf(s0[r], sl2, -li));
+          P1[c][r] = __builtin_amdgcn_exp2f(fmaf(s1[r], sl2, -li));
+          dpart = fmaf(P0[c][r], G0[c][r], dpart);
+          dpart = fmaf(P1[c][r], G1[c][r], dpart);
+        }
+      }
+      const float Di = group_sum(dpart);   // the keys of a query are spread over the four lane groups
+      if (g == 0) sD[qt * 16 + i] = Di;    // phase B reads it per query
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        f32x4 d0, d1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          d0[r] = P0[c][r] * (G0[c][r] - Di);
+          d1[r] = P1[c][r] * (G1[c][r] - Di);
+        }
+        const bf16x8 dsf = pack8(d0, d1);
+#pragma unroll
+        for (int dt = 0; dt < AT<HD>::NDT; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD, CL>(sK, c * 32, dt * 16, lane, rmax), dsf, dq[dt], 0, 0, 0);
+      }
+    } else {
+    const float Di = sD[qt * 16 + i];
 #pragma unroll
     for (int c = 0; c < nchunks; ++c) {
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
 #pragma unroll
       for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32, ks, lane), qf[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sK, c * 32 + 16, ks, lane), qf[ks], s1, 0, 0, 0);
-        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sV, c * 32, ks, lane), dof[ks], p0, 0, 0, 0);
-        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sV, c * 32 + 16, ks, lane), dof[ks], p1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sK, c * 32, ks, lane, rmax), qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sK, c * 32 + 16, ks, lane, rmax), qf[ks], s1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sV, c * 32, ks, lane, rmax), dof[ks], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sV, c * 32 + 16, ks, lane, rmax), dof[ks], p1, 0, 0, 0);
       }
       const int j0 = c * 32 + 4 * g;
       if (NCH > 0 ? c == NCH - 1 : c * 32 + 32 > T) {  // only the last chunk holds keys past T (static when unrolled, else wave-uniform)
@@ -426,7 +493,8 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
       const bf16x8 dsf = pack8(s0, s1);
 #pragma unroll
       for (int dt = 0; dt < AT<HD>::NDT; ++dt)
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sK, c * 32, dt * 16, lane), dsf, dq[dt], 0, 0, 0);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD, CL>(sK, c * 32, dt * 16, lane, rmax), dsf, dq[dt], 0, 0, 0);
+    }
     }
     const int tq = qt * 16 + i;
     if (tq < T) {
@@ -435,6 +503,7 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
         if (dt * 16 + 4 * g < hdv) AT_ST(dbase + tq * gs + dt * 16 + 4 * g, dq[dt] * scale);
     }
   }
+  if (DPM) __syncthreads();   // every query's D is in sD before the key-owner phase reads it
 
   // ---- phase B: wave owns 16 keys; dV^T[d][j] = sum_i dO^T[d][i] P[i][j], dK^T[d][j] = sum_i Q^T[d][i] dS[i][j]
 #ifdef MAE_DBG_ATT_NO_B
@@ -445,8 +514,8 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
     bf16x8 kf[AT<HD>::NKS], vf[AT<HD>::NKS];
 #pragma unroll
     for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
-      kf[ks] = PH == 2 ? rowfrag_global<HD>(base + os, gs, jt * 16, ks, lane, T) : rowfrag<HD>(sK, jt * 16, ks, lane);
-      vf[ks] = PH == 2 ? rowfrag_global<HD>(base + 2 * os, gs, jt * 16, ks, lane, T) : rowfrag<HD>(sV, jt * 16, ks, lane);
+      kf[ks] = PH == 2 ? rowfrag_global<HD>(base + os, gs, jt * 16, ks, lane, T) : rowfrag<HD, CL>(sK, jt * 16, ks, lane, rmax);
+      vf[ks] = PH == 2 ? rowfrag_global<HD>(base + 2 * os, gs, jt * 16, ks, lane, T) : rowfrag<HD, CL>(sV, jt * 16, ks, lane, rmax);
     }
     f32x4 dk[AT<HD>::NDT], dv[AT<HD>::NDT];
 #pragma unroll
@@ -456,10 +525,10 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
 #pragma unroll
       for (int ks = 0; ks < AT<HD>::NKS; ++ks) {
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sQ, c * 32, ks, lane), kf[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sQ, c * 32 + 16, ks, lane), kf[ks], s1, 0, 0, 0);
-        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sdO, c * 32, ks, lane), vf[ks], p0, 0, 0, 0);
-        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD>(sdO, c * 32 + 16, ks, lane), vf[ks], p1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sQ, c * 32, ks, lane, rmax), kf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sQ, c * 32 + 16, ks, lane, rmax), kf[ks], s1, 0, 0, 0);
+        p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sdO, c * 32, ks, lane, rmax), vf[ks], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rowfrag<HD, CL>(sdO, c * 32 + 16, ks, lane, rmax), vf[ks], p1, 0, 0, 0);
       }
       // lane: key j = jt*16 + i; queries c*32 + 4g + r (tile 0), c*32 + 16 + 4g + r (tile 1); padded queries: lse = 1e30
       const f32x4 l0 = load4(sLse + c * 32 + 4 * g), l1 = load4(sLse + c * 32 + 16 + 4 * g);
@@ -475,8 +544,8 @@ __global__ void __launch_bounds__(BwdCap<NCH>::v) attn_bwd_mfma_kernel(const bf1
       const bf16x8 pf = pack8(s0, s1), dsf = pack8(ds0, ds1);
 #pragma unroll
       for (int dt = 0; dt < AT<HD>::NDT; ++dt) {
-        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sdO, c * 32, dt * 16, lane), pf, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD>(sQ, c * 32, dt * 16, lane), dsf, dk[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD, CL>(sdO, c * 32, dt * 16, lane, rmax), pf, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(trfrag<HD, CL>(sQ, c * 32, dt * 16, lane, rmax), dsf, dk[dt], 0, 0, 0);
       }
     }
     const int tj = jt * 16 + i;
@@ -528,6 +597,8 @@ template <int HD, int NCH>
 static int launch_attn_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, const float* lse, int B, int T, int Tp, int H, int hdv, size_t lds,
                            float scale, bf16* d_qkv, hipStream_t s) {
   auto kern = attn_bwd_mfma_kernel<HD, NCH>;
+  static const int lds_pad = [] { const char* e = getenv("MAE_ATT_LDS_PAD"); return e ? atoi(e) : 0; }();   // residency experiment: extra LDS bytes per workgroup
+  lds += (size_t)lds_pad;
   MAE_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)B * H), dim3(64 * attn_waves(T, BwdCap<NCH>::v)), lds, s, qkv, out, d_out, lse, T, Tp, H, scale, d_qkv, attn_stagger(), 256 * attn_resident(lds, 64 * attn_waves(T, BwdCap<NCH>::v)), hdv, attn_remap());
   MAE_LAUNCH_CHECK();
@@ -573,7 +644,7 @@ static int launch_attn_fwd_fq(const bf16* qkv, int B, int T, int Tp, int H, int 
 int mfma_attention_fwd(const bf16* qkv, int B, int T, int H, int hd, bf16* out, float* lse, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return MFMA_UNSUPPORTED;
   const int Tp = (int)round_up(T, 32), hdt = hd == 24 ? 32 : hd;
-  const size_t img = (size_t)round_up((int64_t)Tp * (hdt * 2 + 32), 1024);
+  const size_t img = (size_t)round_up(((Tp >> 5) <= 3 ? round_up((int64_t)T, 16) : (int64_t)Tp) * (hdt * 2 + 32), 1024);   // the short unrolled variants hold round_up(T, 16) rows
   const size_t lds = 3 * img;
   const float scale = 1.0f / sqrtf((float)hd);
   if (lds > 160 * 1024) {   // three images do not fit: K and V only, query fragments from global memory
@@ -587,7 +658,7 @@ int mfma_attention_bwd(const bf16* qkv, const bf16* out, const bf16* d_out, cons
                        bf16* d_qkv, hipStream_t s) {
   if (!attn_supported(T, H, hd) || (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)d_out | (uintptr_t)d_qkv) & 15)) return MFMA_UNSUPPORTED;
   const int Tp = (int)round_up(T, 32), hdt = hd == 24 ? 32 : hd;
-  const size_t img = (size_t)round_up((int64_t)Tp * (hdt * 2 + 32), 1024);
+  const size_t img = (size_t)round_up(((Tp >> 5) <= 3 ? round_up((int64_t)T, 16) : (int64_t)Tp) * (hdt * 2 + 32), 1024);   // the short unrolled variants hold round_up(T, 16) rows
   const size_t lds = 4 * img + (size_t)2 * Tp * 4;
   const float scale = 1.0f / sqrtf((float)hd);
   if (lds > 160 * 1024) {
