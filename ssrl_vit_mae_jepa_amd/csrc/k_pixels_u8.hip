@@ -49,6 +49,17 @@ __device__ __forceinline__ void band_tokens(const I* __restrict__ tok, int64_t b
   }
 }
 
+// the list in ascending order (entries are distinct): a kernel that SUMS over the band's tokens then adds them in an order that does
+// not depend on which thread won which slot -- the loss comes out bit-identical from run to run
+__device__ __forceinline__ void sort_band_list(const int* list, int n, int* sorted) {
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int v = list[i];
+    int rank = 0;
+    for (int o = 0; o < n; ++o) rank += list[o] < v;
+    sorted[rank] = v;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -115,6 +126,7 @@ __global__ void __launch_bounds__(256) mse_images_u8_kernel(const float* __restr
                                                             float gscale, float* __restrict__ partial, T* __restrict__ dpred) {
   extern __shared__ __attribute__((aligned(16))) unsigned lds32[];
   int* list = reinterpret_cast<int*>(lds32 + C * p * (img >> 2));
+  int* sorted = list + m;   // the band's token list in ascending order
   __shared__ int cnt;
   __shared__ float red[4];
   const int g = img / p, P = C * p * p, p4 = p >> 2, units = p * p4;
@@ -129,9 +141,11 @@ __global__ void __launch_bounds__(256) mse_images_u8_kernel(const float* __restr
     band_tokens(mask32, b, m, g, ph, false, list, &cnt);
     __syncthreads();
     const int n = cnt;
+    sort_band_list(list, n, sorted);
+    __syncthreads();
     for (int it = threadIdx.x; it < n * units; it += 256) {
       const int li = it / units, u = it - li * units;
-      const int j = list[li] >> 8, pw = list[li] & 0xff;
+      const int j = sorted[li] >> 8, pw = sorted[li] & 0xff;
       const int py = u / p4, px = (u - py * p4) << 2;
       const int64_t o = (b * m + j) * (int64_t)P + (py * p + px) * C;  // 4 pixels x C channels = 4C contiguous elements
       const uint8_t* src = band + py * img + pw * p + px;
@@ -168,7 +182,7 @@ int launch_mse_from_images_u8(const float* pred, const uint8_t* images, const in
   const int64_t n = (int64_t)B * m * p * p * C;
   const int grid = (int)std::min<int64_t>((int64_t)B * (img / p), 1024);  // stage-1 partials: scratch holds 1024 floats + 8
   const float gs = grad_scale * 2.0f / (float)n;
-  const size_t lds = (size_t)C * p * img + (size_t)m * 4;
+  const size_t lds = (size_t)C * p * img + (size_t)m * 8;   // band + token list + its sorted copy
   if (lds > 64 * 1024) {
     MAE_HIP(hipFuncSetAttribute((const void*)mse_images_u8_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MAE_HIP(hipFuncSetAttribute((const void*)mse_images_u8_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
