@@ -87,9 +87,10 @@ template <class V> __device__ __forceinline__ void stream_store(V v, V* p) {
 // fp32 rows, whose two 16-byte halves per lane go out in two instructions.  Non-temporal partial lines are not merged in L2 and reach HBM
 // piece by piece: PMC WRITE_SIZE shows +10-11 % on every bf16 launch and +25-33 % on the fp32 ones, 2.1 GB per step; with ordinary stores
 // for those pieces (-DMAE_NT3_PART_STORE=1) the counter equals the algorithmic bytes exactly (step 98.6 -> 96.5 GB) but the step is 0.07-0.13 ms
-// SLOWER (linear_nt 10.12 -> 10.22 ms, 2 x A/B on one box: the dirty lines now wait in L2 for their other half).  Time wins: nt everywhere.
+// SLOWER (linear_nt 10.12 -> 10.22 ms, 2 x A/B on one box: the dirty lines now wait in L2 for their other half).  Time wins: nt for the bf16
+// half-lines.  The fp32 rows are different: ordinary stores take the two fp32-output launches of a step from 55.2 to 42.9 us (= 2, the default).
 #ifndef MAE_NT3_PART_STORE
-#define MAE_NT3_PART_STORE 0
+#define MAE_NT3_PART_STORE 2
 #endif
 template <class V> __device__ __forceinline__ void part_store(V v, V* p) {
 #if MAE_NT3_PART_STORE == 1
@@ -99,8 +100,13 @@ template <class V> __device__ __forceinline__ void part_store(V v, V* p) {
 #endif
 }
 __device__ __forceinline__ void st8(float* p, const f32x4& a, const f32x4& b) {
+#if MAE_NT3_PART_STORE == 2   // ordinary stores for the fp32 rows only
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+#else
   part_store(a, reinterpret_cast<f32x4*>(p));
   part_store(b, reinterpret_cast<f32x4*>(p + 4));
+#endif
 }
 __device__ __forceinline__ bf16x8 pk8(const f32x4& a, const f32x4& b) {
   return bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};

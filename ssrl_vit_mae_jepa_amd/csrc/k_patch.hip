@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) decoder_assemble_kernel(const T* __restri
                                                                const float* __restrict__ pos, int64_t rows, int k, int L,
                                                                int D4, float* __restrict__ out) {
   // D4 threads per row, 256 / D4 rows per block pass: 32-bit index math only (a 64-bit divide per element made this
-  // kernel run at half the HBM rate), the fp32 output is streamed
+  // kernel run at half the HBM rate)
   const int rpb = 256 / D4, ro = threadIdx.x / D4, d = (threadIdx.x - ro * D4) * 4;
   if (ro >= rpb) return;
   // four rows per thread and pass: the row's index, then its source row, are two dependent round trips -- with one row in flight per
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) decoder_assemble_kernel(const T* __restri
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t r = r0 + u * stride;
-      if (r < rows) store4_nt(out + r * (D4 * 4) + d, v[u] + pz[u]);
+      if (r < rows) store4(out + r * (D4 * 4) + d, v[u] + pz[u]);   // (ordinary stores: 74.6 us against 77.1 non-temporal)
     }
   }
 }
