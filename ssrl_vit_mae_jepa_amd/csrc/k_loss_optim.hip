@@ -5,6 +5,7 @@
 //   adamw          == torch.optim.AdamW(lr, betas=(.9,.999), eps=1e-8, weight_decay) single group
 //                                                                          (src/training/mae.py:59-65)
 #include "kernels.h"
+#include <cstdlib>
 
 namespace mae {
 
@@ -91,6 +92,11 @@ int launch_mse_from_images(const float* pred, const float* images, const int32_t
                            int p, float grad_scale, float* loss, void* d_pred, int dpred_dt, float* scratch,
                            hipStream_t s) {
   MAE_REQUIRE(pred && images && mask32 && loss && scratch && B > 0 && m > 0 && img % p == 0, "mse_from_images: bad arguments");
+  {
+    static const bool band = [] { const char* v = getenv("MAE_MSE_BAND"); return !v || v[0] != '0'; }();   // MAE_MSE_BAND=0: the per-pixel gather (A/B)
+    const int r = band ? launch_mse_from_images_band_f32(pred, images, mask32, B, m, C, img, p, grad_scale, loss, d_pred, dpred_dt, scratch, s) : -1;
+    if (r >= 0) return r;
+  }
   const int64_t rows = (int64_t)B * m;
   const int64_t n = rows * p * p * C;
   const int grid = (int)std::min<int64_t>(cdiv(rows * p * p, 256), RED_BLOCKS);

@@ -201,6 +201,86 @@ int launch_mse_from_images_u8(const float* pred, const uint8_t* images, const in
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same band walk for NORMALISED FLOAT images (the parity format): one workgroup streams one row of patches ([C][p][W] floats)
+// into LDS with coalesced loads and serves the band's masked tokens from there.  The per-(row, pixel) gather it replaces pulled
+// 759 MB for 221 MB of pixels at batch 2000 (32-byte patch rows out of 128-byte lines, PMC round 3).
+// ---------------------------------------------------------------------------------------------------
+template <class T, bool HAS_GRAD>
+__global__ void __launch_bounds__(256) mse_images_band_f32_kernel(const float* __restrict__ pred, const float* __restrict__ images,
+                                                                  const int32_t* __restrict__ mask32, int B, int m, int C, int img, int p,
+                                                                  float gscale, float* __restrict__ partial, T* __restrict__ dpred) {
+  extern __shared__ __attribute__((aligned(16))) unsigned lds32[];
+  float* band = reinterpret_cast<float*>(lds32);
+  int* list = reinterpret_cast<int*>(lds32 + C * p * img);
+  int* sorted = list + m;
+  __shared__ int cnt;
+  __shared__ float red[4];
+  const int g = img / p, P = C * p * p, p4 = p >> 2, units = p * p4, w4 = img >> 2;
+  float acc = 0.f;
+  for (int64_t bb = blockIdx.x; bb < (int64_t)B * g; bb += gridDim.x) {
+    const int64_t b = bb / g;
+    const int ph = (int)(bb - b * g);
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    for (int w = threadIdx.x; w < C * p * w4; w += 256) {   // 16 bytes per thread: a band row is W floats, contiguous in the image
+      const int row = w / w4, col = w - row * w4;
+      const int c = row / p, py = row - c * p;
+      store4(band + row * img + col * 4, load4(images + ((b * C + c) * (int64_t)img + (ph * p + py)) * img + col * 4));
+    }
+    band_tokens(mask32, b, m, g, ph, false, list, &cnt);
+    __syncthreads();
+    const int n = cnt;
+    sort_band_list(list, n, sorted);
+    __syncthreads();
+    for (int it = threadIdx.x; it < n * units; it += 256) {
+      const int li = it / units, u = it - li * units;
+      const int j = sorted[li] >> 8, pw = sorted[li] & 0xff;
+      const int py = u / p4, px = (u - py * p4) << 2;
+      const int64_t o = (b * m + j) * (int64_t)P + (py * p + px) * C;  // 4 pixels x C channels = 4C contiguous elements
+      const float* src = band + py * img + pw * p + px;
+      for (int v = 0; v < C; ++v) {
+        const f32x4 pr = load4(pred + o + 4 * v);
+        f32x4 d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int e = 4 * v + i, pxi = e / C, c = e - pxi * C;
+          d[i] = pr[i] - src[c * p * img + pxi];
+          acc += d[i] * d[i];
+        }
+        if (HAS_GRAD) store4(dpred + o + 4 * v, d * gscale);
+      }
+    }
+    __syncthreads();
+  }
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// returns -1 when the geometry does not fit the band walk (the caller then takes the per-pixel gather)
+int launch_mse_from_images_band_f32(const float* pred, const float* images, const int32_t* mask32, int B, int m, int C, int img, int p,
+                                    float grad_scale, float* loss, void* d_pred, int dpred_dt, float* scratch, hipStream_t s) {
+  if (!(p > 0 && img % p == 0 && p % 4 == 0 && img / p <= 64 && (int64_t)C * p * img * 4 <= 96 * 1024 && m <= 8192)) return -1;
+  if ((((uintptr_t)pred | (uintptr_t)images | (uintptr_t)d_pred) & 15) != 0 || (C * p * p) % 4 != 0) return -1;
+  const int64_t n = (int64_t)B * m * p * p * C;
+  const int grid = (int)std::min<int64_t>((int64_t)B * (img / p), 1024);  // stage-1 partials: scratch holds 1024 floats + 8
+  const float gs = grad_scale * 2.0f / (float)n;
+  const size_t lds = (size_t)C * p * img * 4 + (size_t)m * 8;
+  MAE_HIP(hipFuncSetAttribute((const void*)mse_images_band_f32_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MAE_HIP(hipFuncSetAttribute((const void*)mse_images_band_f32_kernel<bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MAE_HIP(hipFuncSetAttribute((const void*)mse_images_band_f32_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (!d_pred)
+    hipLaunchKernelGGL((mse_images_band_f32_kernel<float, false>), dim3(grid), dim3(256), lds, s, pred, images, mask32, B, m, C, img, p, gs, scratch, (float*)nullptr);
+  else if (dpred_dt == MAE_BF16)
+    hipLaunchKernelGGL((mse_images_band_f32_kernel<bf16, true>), dim3(grid), dim3(256), lds, s, pred, images, mask32, B, m, C, img, p, gs, scratch, (bf16*)d_pred);
+  else
+    hipLaunchKernelGGL((mse_images_band_f32_kernel<float, true>), dim3(grid), dim3(256), lds, s, pred, images, mask32, B, m, C, img, p, gs, scratch, (float*)d_pred);
+  MAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mean_finalize_u8_kernel, dim3(1), dim3(256), 0, s, scratch, grid, 1.0f / (float)n, loss);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // target (B*m, P) fp32 in (py, px, c) order for patch max(mask - 1, 0): utils.patchify + get_at_index on uint8 pixels
 // ---------------------------------------------------------------------------------------------------
 template <class I>

@@ -68,6 +68,9 @@ int launch_sum_partials(const float* partial, int G, int C, float* out0, float* 
 int launch_mse(const float* pred, const float* target, int64_t n, float grad_scale, float* loss, void* d_pred,
                int dpred_dt, float* scratch, hipStream_t s);
 // same with the target read straight from the image (never materialised)
+// band walk for float images (k_pixels_u8.hip); -1 = geometry not covered
+int launch_mse_from_images_band_f32(const float* pred, const float* images, const int32_t* mask32, int B, int m, int C, int img, int p,
+                                    float grad_scale, float* loss, void* d_pred, int dpred_dt, float* scratch, hipStream_t s);
 int launch_mse_from_images(const float* pred, const float* images, const int32_t* mask32, int B, int m, int C, int img,
                            int p, float grad_scale, float* loss, void* d_pred, int dpred_dt, float* scratch,
                            hipStream_t s);
