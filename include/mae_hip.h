@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MAE_ABI_VERSION 3
+#define MAE_ABI_VERSION 4
 
 enum { MAE_F32 = 0, MAE_BF16 = 1, MAE_U8 = 2 /* images only */ };
 
@@ -221,6 +221,22 @@ int mae_engine_jepa_loss_and_grads(mae_engine_t* e, const float* params, const v
                                    float grad_scale, void* workspace, int64_t workspace_bytes, float* grads,
                                    float* loss_out, float* h_out, float* pred_out, void* const* ready_events,
                                    int32_t num_ready, void* stream);
+/* The optimizer on a SHARD of the parameter arena (ABI v4; data-parallel ranks that each own 1 / world of the trainable range, the
+ * reduce-scatter -> shard sum of squares -> scalar all-reduce -> AdamW on the shard -> all-gather scheme).  The reference runs one
+ * replicated clip_grad_norm_ + AdamW (scripts/training/pretrain_mae.py:124-125, src/training/mae.py:59-65); these three calls are that
+ * step cut at the two points where ranks have to talk.  lo, count: float offsets into the arenas, multiples of 4, inside
+ * [0, mae_engine_trainable_elems).
+ *   mae_engine_grad_sumsq_range: sumsq_out[0] = sum of grads[lo .. lo+count)^2 (count may be 0)
+ *   mae_engine_clip_from_sumsq : stats_out = {sqrt(sumsq[0]), min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))} -- after the ranks' sums were added
+ *   mae_engine_adamw_range     : AdamW on [lo, lo+count) with gradients scaled by stats[1]; writes the bf16 operand copy of that range only.
+ *                                Call mae_engine_refresh_weights once the shards have been gathered. */
+int mae_engine_grad_sumsq_range(mae_engine_t* e, const float* grads, int64_t lo, int64_t count, float* sumsq_out, float* scratch,
+                                void* stream);
+int mae_engine_clip_from_sumsq(mae_engine_t* e, const float* sumsq, float max_norm, float* stats_out, void* stream);
+int mae_engine_adamw_range(mae_engine_t* e, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* stats,
+                           int64_t lo, int64_t count, void* stream);
+
 /* mae_engine_optimizer_step with the EMA update of the target encoder fused into the AdamW sweep:
  * target[0 .. encoder_grad_elems) = m * target + (1 - m) * params_new (+ the bf16 operand copy in target_wcache).
  * max_norm = +inf disables clipping (I-JEPA trains unclipped). */

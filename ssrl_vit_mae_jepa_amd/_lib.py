@@ -18,7 +18,7 @@ MAE_F32, MAE_BF16, MAE_U8 = 0, 1, 2
 PARAM_TRAINABLE, PARAM_FROZEN, PARAM_UNUSED, PARAM_MATRIX = 1, 2, 4, 8
 LOSS_MSE, LOSS_SMOOTH_L1 = 0, 1
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_DGELU, EPI_GELU_GRAD, EPI_MUL, EPI_GELU_ACT = 0, 1, 2, 3, 4, 5, 6
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class MaeConfig(C.Structure):
@@ -77,6 +77,9 @@ SIGNATURES = {
     "mae_engine_jepa_workspace_bytes": (_i64, [_vp, _i32, _i32, _i32, _i32]),
     "mae_engine_jepa_loss_and_grads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64,
                                                  _vp, _vp, _vp, _vp, _pp(_vp), _i32, _vp]),
+    "mae_engine_grad_sumsq_range": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "mae_engine_clip_from_sumsq": (C.c_int, [_vp, _vp, _f32, _vp, _vp]),
+    "mae_engine_adamw_range": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _i64, _i64, _vp]),
     "mae_engine_optimizer_step_ema": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _vp, _vp, _vp, _f32, _vp]),
     "mae_engine_timers_enable": (C.c_int, [_vp, _i32]),
     "mae_engine_timer_count": (_i32, [_vp]),

@@ -999,6 +999,40 @@ extern "C" int mae_engine_optimizer_step(mae_engine_t* e, float* params, float* 
                              scratch, nullptr, nullptr, 0.f, stream);
 }
 
+// ---- optimizer on a shard of the arena (data-parallel ranks that own 1 / world of the parameters) ----------------
+extern "C" int mae_engine_grad_sumsq_range(mae_engine_t* e, const float* grads, int64_t lo, int64_t count, float* sumsq_out, float* scratch,
+                                           void* stream) {
+  MAE_REQUIRE(e && grads && sumsq_out && scratch, "mae_engine_grad_sumsq_range: null argument");
+  MAE_REQUIRE(lo >= 0 && count >= 0 && lo % 4 == 0 && count % 4 == 0 && lo + count <= e->trainable_elems,
+              "mae_engine_grad_sumsq_range: range [%lld, +%lld) outside the %lld trainable elements or not a multiple of 4", (long long)lo,
+              (long long)count, (long long)e->trainable_elems);
+  return launch_grad_sumsq(grads + lo, count, sumsq_out, scratch, (hipStream_t)stream);
+}
+
+extern "C" int mae_engine_clip_from_sumsq(mae_engine_t* e, const float* sumsq, float max_norm, float* stats_out, void* stream) {
+  MAE_REQUIRE(e && sumsq && stats_out, "mae_engine_clip_from_sumsq: null argument");
+  return launch_clip_from_sumsq(sumsq, max_norm, stats_out, (hipStream_t)stream);
+}
+
+extern "C" int mae_engine_adamw_range(mae_engine_t* e, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,
+                                      float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, const float* stats,
+                                      int64_t lo, int64_t count, void* stream) {
+  MAE_REQUIRE(e && params && grads && exp_avg && exp_avg_sq && stats, "mae_engine_adamw_range: null argument");
+  MAE_REQUIRE(step >= 1, "mae_engine_adamw_range: step is 1-based");
+  MAE_REQUIRE(lo >= 0 && count >= 0 && lo % 4 == 0 && count % 4 == 0 && lo + count <= e->trainable_elems,
+              "mae_engine_adamw_range: range [%lld, +%lld) outside the %lld trainable elements or not a multiple of 4", (long long)lo,
+              (long long)count, (long long)e->trainable_elems);
+  MAE_REQUIRE(e->act == MAE_F32 || wcache, "mae_engine_adamw_range: bf16 engine needs the weight cache");
+  if (count == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const float bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+  const float bc2 = (float)(1.0 - std::pow((double)beta2, (double)step));
+  RUN(TK_OPTIM, 0, count * (28 + (e->act == MAE_BF16 ? 2 : 0)),
+      launch_adamw(params + lo, grads + lo, exp_avg + lo, exp_avg_sq + lo, count, lr, beta1, beta2, eps, weight_decay, bc1, bc2, stats,
+                   e->act == MAE_BF16 ? reinterpret_cast<bf16*>(wcache) + lo : nullptr, s));
+  return 0;   // the bf16 operand copies of the OTHER ranks' shards and the transposes: mae_engine_refresh_weights after the all-gather
+}
+
 extern "C" int mae_engine_optimizer_step_ema(mae_engine_t* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* wcache,
                                              float lr, float beta1, float beta2, float eps, float weight_decay, float max_norm, int64_t step,
                                              float* stats_out, float* scratch, float* target_params, void* target_wcache,

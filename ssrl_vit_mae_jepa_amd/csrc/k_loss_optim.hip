@@ -140,6 +140,36 @@ __global__ void __launch_bounds__(256) norm_finalize_kernel(const float* __restr
   }
 }
 
+// the two halves of launch_grad_norm for a gradient that is sharded over ranks: sum of squares of a range, then (after the ranks'
+// sums were added) norm + clip coefficient from the total
+__global__ void __launch_bounds__(256) sumsq_finalize_kernel(const float* __restrict__ partial, int nb, float* __restrict__ out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
+  acc = block_sum_256(acc, red);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+__global__ void clip_from_sumsq_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ stats) {
+  const float total = sqrtf(sumsq[0]);
+  stats[0] = total;
+  stats[1] = fminf(max_norm / (total + 1e-6f), 1.0f);
+}
+int launch_grad_sumsq(const float* g, int64_t n, float* out, float* scratch, hipStream_t s) {
+  MAE_REQUIRE(g && out && scratch && n >= 0 && n % 4 == 0, "grad_sumsq: need n %% 4 == 0 and non-null buffers");
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(n / 4, 256), RED_BLOCKS));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, g, n / 4, scratch);   // n == 0: every partial is zero
+  MAE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_finalize_kernel, dim3(1), dim3(256), 0, s, scratch, grid, out);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+int launch_clip_from_sumsq(const float* sumsq, float max_norm, float* stats, hipStream_t s) {
+  MAE_REQUIRE(sumsq && stats, "clip_from_sumsq: null argument");
+  hipLaunchKernelGGL(clip_from_sumsq_kernel, dim3(1), dim3(1), 0, s, sumsq, max_norm, stats);
+  MAE_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_grad_norm(const float* g, int64_t n, float max_norm, float* stats, float* scratch, hipStream_t s) {
   MAE_REQUIRE(g && stats && scratch && n > 0 && n % 4 == 0, "grad_norm: need n %% 4 == 0 and non-null buffers");
   const int grid = (int)std::min<int64_t>(cdiv(n / 4, 256), RED_BLOCKS);

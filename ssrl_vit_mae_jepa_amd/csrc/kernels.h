@@ -76,6 +76,8 @@ int launch_mse_from_images(const float* pred, const float* images, const int32_t
                            hipStream_t s);
 // stats[0] = ||g||_2, stats[1] = min(1, max_norm/(norm+1e-6)).  scratch >= 1024+ floats
 int launch_grad_norm(const float* g, int64_t n, float max_norm, float* stats, float* scratch, hipStream_t s);
+int launch_grad_sumsq(const float* g, int64_t n, float* out, float* scratch, hipStream_t s);
+int launch_clip_from_sumsq(const float* sumsq, float max_norm, float* stats, hipStream_t s);
 // AdamW with g scaled by stats[1]; optionally refresh bf16 copy of the params (wbf may be null)
 // ema_target != null: target[0 .. ema_n) = ema_momentum * target + (1 - ema_momentum) * p_new in the same sweep (+ its bf16 copy)
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,

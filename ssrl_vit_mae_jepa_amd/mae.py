@@ -343,7 +343,8 @@ class MaskedAutoencoder(nn.Module):
     def flat_params(self) -> torch.Tensor:
         return self._arena
 
-    GRAD_TAIL = 64  # floats behind the gradients: slot 0 carries the step's loss through the data-parallel all-reduce
+    GRAD_TAIL = 64 + 64 * 64  # floats behind the gradients: slot 0 carries the step's loss through the data-parallel all-reduce; the rest pads the
+    #                           arena to world equal shards for the sharded optimizer (MAE_DP_SHARDED_OPT=1: up to 64 ranks of 64-float granules)
 
     @property
     def grad_buffer(self) -> torch.Tensor:

@@ -21,6 +21,7 @@ from typing import Any, Dict, List, Optional, Tuple
 import torch
 from torch import nn
 
+from . import _lib
 from ._lib import check, lib
 from .mae import MaskedAutoencoder, _ptr, _stream
 
@@ -214,6 +215,69 @@ class MAEPretrainModule(nn.Module):
             dist.all_reduce(buf[:n + 1], op=dist.ReduceOp.SUM, group=process_group)
         return loss_slot * 1.0  # sum over ranks of (share x local mean) = the global mean; a copy: the slot is rewritten next step
 
+    # ---- sharded optimizer (MAE_DP_SHARDED_OPT=1): reduce-scatter -> shard sum of squares -> scalar all-reduce -> AdamW on the shard -> all-gather
+    def _sharded_opt_world(self, process_group) -> int:
+        dist = torch.distributed
+        if os.environ.get("MAE_DP_SHARDED_OPT") != "1" or not (dist.is_available() and dist.is_initialized()):
+            return 0
+        world = dist.get_world_size(process_group)
+        return world if world > 1 or os.environ.get("MAE_DP_FORCE_EXCHANGE") == "1" else 0
+
+    def _sharded_step(self, compute, process_group, weight: Optional[float], lr: Optional[float], world: int) -> torch.Tensor:
+        """The data-parallel step with the optimizer sharded over the ranks: every rank owns 1 / world of the
+        trainable arena (64-float granules), receives only that slice of the summed gradient (reduce-scatter: half the bytes of
+        an all-reduce), adds its slice's sum of squares to the others' (one scalar all-reduce: clip_grad_norm_ needs the norm of
+        the WHOLE gradient), runs AdamW on the slice and all-gathers the updated parameters (the other half).  Same result as
+        the replicated step up to the order in which the squares are summed (one ulp of the clip coefficient).  No overlap with
+        the backward pass: the exchange is one collective over the padded arena."""
+        model = self.model
+        dev = model._require_cuda()
+        dist = torch.distributed
+        rank = dist.get_rank(process_group)
+        n = model.engine.trainable_elems
+        shard = ((n + world - 1) // world + 63) // 64 * 64          # ceil(n / world) rounded up to 64 floats
+        npad = shard * world
+        buf, arena = model.grad_buffer, model.flat_params
+        if npad + 1 > buf.numel() or npad > arena.numel():
+            raise RuntimeError(f"sharded optimizer: {world} ranks need {npad - n} floats of padding behind the {n} trainable elements")
+        w = 1.0 / world if weight is None else float(weight)
+        loss_slot = buf[n:n + 1]
+        if compute is None:
+            buf[:n + 1].zero_()
+        else:
+            compute(w, None, loss_slot)
+            loss_slot.mul_(w)
+        loss = loss_slot.clone()            # the slot lies inside the last rank's slice: the loss travels on its own
+        dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=process_group)
+        loss_slot.zero_()                   # not a gradient: keep it out of the reduce-scatter's last slice
+        lo = rank * shard
+        own = buf[lo:lo + shard]
+        nccl = dist.get_backend(process_group) == "nccl"
+        if nccl:
+            dist.reduce_scatter_tensor(own, buf[:npad], op=dist.ReduceOp.SUM, group=process_group)   # in place: own is this rank's slice of the input
+        else:                               # gloo (CPU rehearsal, one-GPU tests) has no reduce-scatter: the sum everywhere, then use the slice
+            dist.all_reduce(buf[:npad], op=dist.ReduceOp.SUM, group=process_group)
+        count = max(0, min(n, lo + shard) - lo)
+        m, v, stats = self._opt_state()
+        self._opt_steps += 1
+        h, st = model.engine.handle, _stream(dev)
+        sumsq = stats[4:5]
+        check(lib.mae_engine_grad_sumsq_range(h, _ptr(model.flat_grads), lo if count else 0, count, _ptr(sumsq), _ptr(model._scratch_f32()), st))
+        dist.all_reduce(sumsq, op=dist.ReduceOp.SUM, group=process_group)
+        check(lib.mae_engine_clip_from_sumsq(h, _ptr(sumsq), float(self.gradient_clip_val), _ptr(stats), st))
+        check(lib.mae_engine_adamw_range(h, _ptr(arena), _ptr(model.flat_grads), _ptr(m), _ptr(v), _ptr(model._weights()),
+                                         float(self.current_lr() if lr is None else lr), 0.9, 0.999, 1e-8, float(self.weight_decay),
+                                         self._opt_steps, _ptr(stats), lo if count else 0, count, st))
+        mine = arena[lo:lo + shard]          # the last rank's slice runs into the frozen tables behind the trainable range: identical on every rank
+        if nccl:
+            dist.all_gather_into_tensor(arena[:npad], mine, group=process_group)
+        else:
+            dist.all_gather([arena[r * shard:(r + 1) * shard] for r in range(world)], mine.clone(), group=process_group)
+        if model.engine.act == _lib.MAE_BF16:   # bf16 copies of the other ranks' slices + every transposed copy
+            check(lib.mae_engine_refresh_weights(h, _ptr(arena), _ptr(model._wcache), st))
+        model.mark_weights_fresh()
+        return loss
+
     def fused_training_step(self, images: torch.Tensor, noise: Optional[torch.Tensor] = None, lr: Optional[float] = None,
                             process_group=None, global_rows: Optional[int] = None) -> torch.Tensor:
         """One whole pretrain step.  With torch.distributed initialised every rank computes its rows of the global batch
@@ -234,8 +298,12 @@ class MAEPretrainModule(nn.Module):
             if noise is None:
                 noise = torch.rand(rows, model.sequence_length, device=dev)
             compute = lambda scale, events, out: model.loss_and_grads(images, noise, grad_scale=scale, ready_events=events, loss_out=out)  # noqa: E731
-        loss = self._exchanged_loss_and_grads(compute, process_group, weight)
-        self.optimizer_step(lr)
+        sharded = self._sharded_opt_world(process_group)
+        if sharded:
+            loss = self._sharded_step(compute, process_group, weight, lr, sharded)
+        else:
+            loss = self._exchanged_loss_and_grads(compute, process_group, weight)
+            self.optimizer_step(lr)
         self.global_step += 1
         self.log("train_loss", loss)
         return loss

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_error_channel():
     from ssrl_vit_mae_jepa_amd import _lib
-    assert _lib.lib.mae_abi_version() == _lib.ABI_VERSION == 3  # v2: image_dtype arguments (uint8 pixels); v3: mae_augment_crop_flip_u8
+    assert _lib.lib.mae_abi_version() == _lib.ABI_VERSION == 4  # v2: image_dtype arguments (uint8 pixels); v3: mae_augment_crop_flip_u8; v4: the optimizer on a shard of the arena
     cfg = _lib.MaeConfig(image_size=96, patch_size=7, in_chans=3, embed_dim=384, depth=12, num_heads=6,
                          decoder_embed_dim=192, decoder_depth=2, decoder_num_heads=6, mlp_ratio=4, act_dtype=1)
     h = ctypes.c_void_p()

@@ -97,3 +97,22 @@ def test_ragged_global_batch_equals_single_process(tmp_path, config, precision, 
     assert rel_err(ov[0]["params"], one["params"]) < tol
     assert torch.allclose(ov[0]["losses"], one["losses"], rtol=1e-5, atol=0)
     assert torch.equal(torch.cat([o["keep0"] for o in ov]), one["keep0"])
+
+
+@pytest.mark.parametrize("config,precision,world,batch,tol", [("micro", "fp32", 2, 8, 2e-6), ("micro", "fp32", 3, 7, 2e-6), ("vits8", "bf16", 2, 8, 2e-5)])
+def test_sharded_optimizer_equals_the_replicated_step(tmp_path, config, precision, world, batch, tol):
+    """MAE_DP_SHARDED_OPT=1: every rank receives its 1 / world slice of the summed gradient, adds its slice's sum of
+    squares to the others', runs AdamW on the slice and all-gathers the parameters.  After two steps every rank holds the same
+    parameters, equal to the replicated step's up to the order in which the squared gradients were summed (the clip coefficient may
+    differ in its last bit), the loss is the same global mean and the reported gradient norm agrees."""
+    a, b = tmp_path / "sharded", tmp_path / "replicated"
+    for d in (a, b):
+        d.mkdir()
+    sh = _run(a, world, config, precision, batch, {"MAE_DP_SHARDED_OPT": "1"})
+    rp = _run(b, world, config, precision, batch, {"MAE_DP_OVERLAP": "0"})
+    for r in range(1, world):
+        assert torch.equal(sh[0]["params"], sh[r]["params"]) and torch.equal(sh[0]["losses"], sh[r]["losses"])
+    assert not torch.equal(sh[0]["params"], torch.zeros_like(sh[0]["params"]))
+    assert rel_err(sh[0]["params"], rp[0]["params"]) < tol
+    assert torch.allclose(sh[0]["losses"], rp[0]["losses"], rtol=1e-6 if precision == "fp32" else 1e-5, atol=0)
+    assert abs(float(sh[0]["stats"][0]) - float(rp[0]["stats"][0])) <= 1e-5 * float(rp[0]["stats"][0])
