@@ -121,6 +121,7 @@ def main(argv=None):
         train_loss = float(loss_sum.item()) / max(1, steps)
         val_loss = float(val[0].item()) / max(1.0, float(val[1].item()))
         dt = time.perf_counter() - t0
+        module.gather_optimizer_state()   # a collective when the optimizer is sharded (MAE_DP_SHARDED_OPT=1): rank 0's checkpoint needs every slice
         if rank == 0:
             rec = dict(epoch=epoch, train_loss=train_loss, val_loss=val_loss, lr=module.current_lr(), mask_ratio=module.model.mask_ratio,
                        images_per_s=seen / dt)

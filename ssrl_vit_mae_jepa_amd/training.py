@@ -276,7 +276,28 @@ class MAEPretrainModule(nn.Module):
         if model.engine.act == _lib.MAE_BF16:   # bf16 copies of the other ranks' slices + every transposed copy
             check(lib.mae_engine_refresh_weights(h, _ptr(arena), _ptr(model._wcache), st))
         model.mark_weights_fresh()
+        self._moments_sharded = (world, shard)   # exp_avg / exp_avg_sq are current on this rank's slice only until gather_optimizer_state()
         return loss
+
+    def gather_optimizer_state(self, process_group=None) -> None:
+        """After sharded steps every rank holds the AdamW moments of its own slice only: all-gather them so that
+        ``optimizer_state_dict()`` / ``checkpoint_dict()`` (usually called on rank 0 alone) see the whole state.  A collective: EVERY
+        rank calls it (the CLI does, once per epoch, before the checkpoint).  A no-op in the replicated mode."""
+        if getattr(self, "_moments_sharded", None) is None:
+            return
+        dist = torch.distributed
+        world, shard = self._moments_sharded
+        rank = dist.get_rank(process_group)
+        m, v, _ = self._opt_state()
+        n = m.numel()
+        for t in (m, v):
+            full = torch.zeros(world * shard, dtype=t.dtype, device=t.device)
+            lo = rank * shard
+            cnt = max(0, min(n, lo + shard) - lo)
+            full[lo:lo + cnt] = t[lo:lo + cnt]
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=process_group)   # slices are disjoint: the sum is the concatenation (works on gloo too)
+            t.copy_(full[:n])
+        self._moments_sharded = None
 
     def fused_training_step(self, images: torch.Tensor, noise: Optional[torch.Tensor] = None, lr: Optional[float] = None,
                             process_group=None, global_rows: Optional[int] = None) -> torch.Tensor:
@@ -317,6 +338,8 @@ class MAEPretrainModule(nn.Module):
         return [(i, strip(n), strip(n) in trainable) for i, (n, _p) in enumerate(self.model.named_parameters())]
 
     def optimizer_state_dict(self) -> Dict[str, Any]:
+        if getattr(self, "_moments_sharded", None) is not None:
+            raise RuntimeError("the AdamW moments are sharded over the ranks (MAE_DP_SHARDED_OPT=1): call gather_optimizer_state() on every rank first")
         m, v, _ = self._opt_state()
         mv, vv = self.model.named_flat_views(m), self.model.named_flat_views(v)
         state = {}

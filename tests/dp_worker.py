@@ -85,7 +85,11 @@ def main() -> None:
                 keep0 = model.random_token_mask(my_images.shape[0], my_noise)[0].cpu() if my_images.shape[0] else torch.zeros(0, model.num_keep(), dtype=torch.int64)
             losses.append(module.fused_training_step(my_images, my_noise, global_rows=B).clone())
     torch.cuda.synchronize()
-    out = {"params": model.flat_params.detach().cpu(), "losses": torch.cat(losses).cpu(), "keep0": keep0,
+    if hasattr(module, "gather_optimizer_state") and a.world > 1:
+        module.gather_optimizer_state()   # sharded optimizer: every rank's slice of the AdamW moments (a no-op otherwise)
+    out = {"exp_avg": module._exp_avg.detach().cpu() if getattr(module, "_exp_avg", None) is not None else torch.zeros(1),
+           "exp_avg_sq": module._exp_avg_sq.detach().cpu() if getattr(module, "_exp_avg_sq", None) is not None else torch.zeros(1),
+           "params": model.flat_params.detach().cpu(), "losses": torch.cat(losses).cpu(), "keep0": keep0,
            "target": model.target_arena.detach().cpu() if jepa else torch.zeros(1),
            "stats": module._stats.cpu(), "buckets": module.gradient_buckets() if a.world > 1 else [],
            "overlap": module.overlap_exchange}

@@ -116,3 +116,6 @@ def test_sharded_optimizer_equals_the_replicated_step(tmp_path, config, precisio
     assert rel_err(sh[0]["params"], rp[0]["params"]) < tol
     assert torch.allclose(sh[0]["losses"], rp[0]["losses"], rtol=1e-6 if precision == "fp32" else 1e-5, atol=0)
     assert abs(float(sh[0]["stats"][0]) - float(rp[0]["stats"][0])) <= 1e-5 * float(rp[0]["stats"][0])
+    # gather_optimizer_state(): every rank then holds the whole AdamW state (what rank 0 writes into a checkpoint)
+    for key in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(sh[0][key], sh[world - 1][key]) and rel_err(sh[0][key], rp[0][key]) < 10 * tol
