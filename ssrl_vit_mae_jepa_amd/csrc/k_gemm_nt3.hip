@@ -518,14 +518,17 @@ static int launch_nt3(const bf16* A, const bf16* W, int64_t M, int N, int K, con
   return 0;
 }
 
-// rounds of tiles on the CUs x rows per tile = time proxy; the 192-row tile must win by a margin (15 % more staged bytes per flop)
+// rounds of tiles on the CUs x rows per tile = time proxy; the 192-row tile must win by a margin: it stages 15 % more bytes per flop and, with two
+// waves across its 192 columns, stores a third of every row as half lines, which the eight-waves-along-M layout of the 256-row tile does not
+// (decoder launches, M = 290000, N = 192: 1152 against 1280 row-rounds, yet 117.6 us on 256-row tiles against 124.2 us; encoder N = 384:
+// 576 against 768 row-rounds, 86.0 against 99.4 us)
 static bool prefer_bm192_3(int64_t M, int N) {
   static const int force = [] { const char* v = getenv("MAE_NT_BM"); return v ? atoi(v) : 0; }();
   if (force == 192) return true;
   if (force == 256) return false;
   const int64_t t256 = cdiv(M, 256) * (N / 192), t192 = cdiv(M, 192) * (N / 192);
   const int64_t c256 = cdiv(t256, num_cus()) * 256, c192 = cdiv(t192, num_cus()) * 192;
-  return c192 * 100 < c256 * 95;
+  return c192 * 100 < c256 * 85;   // (95 and 85 measure the same in the step: 10.03 ms of NT GEMMs either way, ViT-B/16 21.83)
 }
 
 template <int MODE, class TO>
