@@ -181,6 +181,7 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
   constexpr int BM = G_::BM, BN = G_::BN, ASTG = G_::ASTG, WSTG = G_::WSTG, SA = G_::SA, SW = G_::SW, NA = G_::NA, NW = G_::NW, GPW = G_::GPW;
   constexpr int NJ = NI / 2, NR = MI + NI;
   constexpr bool TWO = MODE == MAE_EPI_GELU_GRAD;
+  constexpr bool KEEP = MODE == 77;   // NONE epilogue with ordinary stores: the output is read by the very next kernel and fits the memory-side cache
   constexpr int STORE8 = sizeof(TO) == 2 ? 1 : 2;          // store instructions per 8 outputs
   constexpr int E = MI * NJ * STORE8 * (TWO ? 2 : 1);      // epilogue stores per wave (full tile)
   static_assert(SW == 2, "the waits below assume weight pieces one step ahead");
@@ -352,11 +353,16 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
           const bf16x8 R = row_swap8(lo8 ? Bv : Av);
           const int col = colw + 32 * (lo8 ? ja : ja + 1);
           const int64_t r1 = mrow + (fr & 7), r2 = r1 + 8;
-          if (r1 < M) stream_store(lo8 ? Av : R, reinterpret_cast<bf16x8*>(dst + r1 * N + col));
-          if (r2 < M) stream_store(lo8 ? R : Bv, reinterpret_cast<bf16x8*>(dst + r2 * N + col));
+          if (KEEP) {
+            if (r1 < M) *reinterpret_cast<bf16x8*>(dst + r1 * N + col) = lo8 ? Av : R;
+            if (r2 < M) *reinterpret_cast<bf16x8*>(dst + r2 * N + col) = lo8 ? R : Bv;
+          } else {
+            if (r1 < M) stream_store(lo8 ? Av : R, reinterpret_cast<bf16x8*>(dst + r1 * N + col));
+            if (r2 < M) stream_store(lo8 ? R : Bv, reinterpret_cast<bf16x8*>(dst + r2 * N + col));
+          }
         };
         auto store_single = [&](TO* __restrict__ dst, const bf16x8& v, int j) {
-          if (m < M) part_store(v, reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j));
+          if (m < M) { if (KEEP) *reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j) = v; else part_store(v, reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j)); }
         };
         if (NJ % 2 == 0) {   // the wave's columns are whole 128-byte lines (128- and 256-wide tiles)
 #pragma unroll
@@ -563,7 +569,14 @@ int mfma_linear_fwd_v3(const bf16* A, const bf16* W, int64_t M, int N, int K, co
   if ((uint64_t)(M + 512) * (uint64_t)K * 2u >= (1ull << 32) || (uint64_t)N * (uint64_t)K * 2u >= (1ull << 32)) return MFMA_UNSUPPORTED;
   const bool f32out = e.out_dt == MAE_F32;
   switch (e.mode) {
-    case MAE_EPI_NONE: return f32out ? launch_nt3_ni<MAE_EPI_NONE, float>(A, W, M, N, K, e, s) : launch_nt3_ni<MAE_EPI_NONE, bf16>(A, W, M, N, K, e, s);
+    case MAE_EPI_NONE: {
+      // bf16 outputs of at most 64 MB (MAE_NT_KEEP=<bytes>; 0 = never) are written with ordinary stores: they stay in the 256 MB memory-side cache for the
+      // LayerNorm / attention kernel that reads them next (proj, fc2 and the dgrads of the 384-wide encoder: LayerNorm forward 1.81 -> 1.78 ms, backward
+      // 2.54 -> 2.50 ms per step, the GEMMs unchanged; at 400 MB the GEMMs lose more than the readers win)
+      static const int64_t keep = [] { const char* v = getenv("MAE_NT_KEEP"); return v ? atoll(v) : 64ll << 20; }();
+      if (!f32out && keep > 0 && M * (int64_t)N * 2 <= keep && N % 256 != 0) return launch_nt3_ni<77, bf16>(A, W, M, N, K, e, s);   // (the 192 x 256 tiles lose 0.6 % with it: ViT-B/16)
+      return f32out ? launch_nt3_ni<MAE_EPI_NONE, float>(A, W, M, N, K, e, s) : launch_nt3_ni<MAE_EPI_NONE, bf16>(A, W, M, N, K, e, s);
+    }
     case MAE_EPI_GELU_GRAD: return f32out ? MFMA_UNSUPPORTED : launch_nt3_ni<MAE_EPI_GELU_GRAD, bf16>(A, W, M, N, K, e, s);
     case MAE_EPI_GELU_ACT: return f32out ? MFMA_UNSUPPORTED : launch_nt3_ni<MAE_EPI_GELU_ACT, bf16>(A, W, M, N, K, e, s);
     case MAE_EPI_MUL: return f32out ? MFMA_UNSUPPORTED : launch_nt3_ni<MAE_EPI_MUL, bf16>(A, W, M, N, K, e, s);
