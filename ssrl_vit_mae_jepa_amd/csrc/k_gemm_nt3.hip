@@ -121,6 +121,17 @@ __device__ __forceinline__ bf16x8 row_swap8(const bf16x8& v) {
   return __builtin_bit_cast(bf16x8, x);
 }
 
+// keep `keep` in the lanes whose 4-lane bank is NOT in BANKS and take `from`'s value of the lane 8 places away (row_ror:8) in the others
+template <int BANKS>
+__device__ __forceinline__ bf16x8 row_merge8(const bf16x8& keep, const bf16x8& from) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+  u32x4_ k = __builtin_bit_cast(u32x4_, keep);
+  const u32x4_ f = __builtin_bit_cast(u32x4_, from);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) k[i] = (unsigned)__builtin_amdgcn_update_dpp((int)k[i], (int)f[i], 0x128, 0xf, BANKS, false);
+  return __builtin_bit_cast(bf16x8, k);
+}
+
 // LDS-DMA pieces from inline asm (the compiler neither counts nor drains them: every wait below is ours).  M0 is written in
 // the statement that uses it.  Raw buffer addressing: byte offset = voff (per lane) + soff (scalar), range-checked against
 // the descriptor's num_records (out of range -> zeros, no fault).
@@ -160,6 +171,13 @@ template <int I0, int I1, int MI, int NI>
 __device__ __forceinline__ void mfma_range(f32x4 (&acc)[MI][NI], const bf16x8 (&a)[MI], const bf16x8 (&b)[NI]) {
 #pragma unroll
   for (int i = I0; i < I1; ++i) acc[i / NI][i % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[i % NI], a[i / NI], acc[i / NI][i % NI], 0, 0, 0);
+}
+
+// the first 32-deep half of a tile: C = 0 inside the instruction instead of 96 zeroed accumulator registers per wave and tile
+template <int I0, int I1, int MI, int NI>
+__device__ __forceinline__ void mfma_range_first(f32x4 (&acc)[MI][NI], const bf16x8 (&a)[MI], const bf16x8 (&b)[NI]) {
+#pragma unroll
+  for (int i = I0; i < I1; ++i) acc[i / NI][i % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[i % NI], a[i / NI], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 }
 
 // MFMAs that follow DMA piece q in phase 1: the MI * NI - (MI + NI) MFMAs left after the read-interleaved ones, spread evenly
@@ -345,20 +363,19 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
           } else {
             pa[j] = pk8(v0, v1);
           }
-          acc[mi][2 * j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          acc[mi][2 * j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         auto store_rows = [&](TO* __restrict__ dst, const bf16x8* pk, int ja) {
-          const bf16x8 Av = pk[ja], Bv = pk[ja + 1];
-          const bf16x8 R = row_swap8(lo8 ? Bv : Av);
+          // S1 = (rows 0-7: own group ja | rows 8-15: the partner's group ja + 1), S2 = (rows 0-7: the partner's group ja | rows 8-15: own group ja + 1):
+          // one DPP move per dword with a bank mask, no selects
+          const bf16x8 S1 = row_merge8<0xc>(pk[ja], pk[ja + 1]), S2 = row_merge8<0x3>(pk[ja + 1], pk[ja]);
           const int col = colw + 32 * (lo8 ? ja : ja + 1);
           const int64_t r1 = mrow + (fr & 7), r2 = r1 + 8;
           if (KEEP) {
-            if (r1 < M) *reinterpret_cast<bf16x8*>(dst + r1 * N + col) = lo8 ? Av : R;
-            if (r2 < M) *reinterpret_cast<bf16x8*>(dst + r2 * N + col) = lo8 ? R : Bv;
+            if (r1 < M) *reinterpret_cast<bf16x8*>(dst + r1 * N + col) = S1;
+            if (r2 < M) *reinterpret_cast<bf16x8*>(dst + r2 * N + col) = S2;
           } else {
-            if (r1 < M) stream_store(lo8 ? Av : R, reinterpret_cast<bf16x8*>(dst + r1 * N + col));
-            if (r2 < M) stream_store(lo8 ? R : Bv, reinterpret_cast<bf16x8*>(dst + r2 * N + col));
+            if (r1 < M) stream_store(S1, reinterpret_cast<bf16x8*>(dst + r1 * N + col));
+            if (r2 < M) stream_store(S2, reinterpret_cast<bf16x8*>(dst + r2 * N + col));
           }
         };
         auto store_single = [&](TO* __restrict__ dst, const bf16x8& v, int j) {
@@ -388,8 +405,6 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
         for (int mi = 0; mi < MI; ++mi) {
           const int64_t m = m0 + wm * WROWS + mi * 16 + fr;
           if (m < M) st8(reinterpret_cast<float*>(out) + m * N + colw + 32 * j, acc[mi][2 * j] + b0, acc[mi][2 * j + 1] + b1);
-          acc[mi][2 * j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          acc[mi][2 * j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
@@ -399,7 +414,6 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
         if (acc[mi][ni][0] == 1.2345e30f) out[0] = (TO)0.f;
-        acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #endif
     prev_full = m0 + BM <= M;
@@ -440,15 +454,17 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
         acc[i / NI][i % NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1[i % NI], af1[i / NI], acc[i / NI][i % NI], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                                           \
     }
-#define NT3_PHASE2()                                                                                               \
+#define NT3_PHASE2_(RANGE)                                                                                         \
     NT3_READ(af1, bf1, sw1)                                                                                        \
-    mfma_range<0, NR>(acc, af0, bf0);                                                                              \
+    RANGE<0, NR>(acc, af0, bf0);                                                                                   \
     NT3_IL(NR)                                                                                                     \
     next_w(); next_a();                                                                                            \
     rd_a = rd_a == rd_a_last ? rd_a - (SA - 1) * ASTG : rd_a + ASTG;                                               \
     rd_w = rd_w == rd_w_last ? rd_w - (SW - 1) * WSTG : rd_w + WSTG;                                               \
-    mfma_range<NR, MI * NI>(acc, af0, bf0);                                                                        \
+    RANGE<NR, MI * NI>(acc, af0, bf0);                                                                             \
     __builtin_amdgcn_sched_barrier(0);
+#define NT3_PHASE2() NT3_PHASE2_(mfma_range)
+#define NT3_PHASE2_FIRST() NT3_PHASE2_(mfma_range_first)   /* a tile's first half: the accumulators start from zero */
 
 #ifdef MAE_DBG_NT3_CLOCK   // alternate build: the in-kernel clock and cycles per K-step of one wave (printf perturbs the launch a little)
   const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
@@ -463,7 +479,7 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
       epilogue((int64_t)p_tm * BM, p_tn * BN, (tile - 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    NT3_PHASE2()
+    NT3_PHASE2_FIRST()
     // ---- the other steps; at the second one the epilogue's stores (counted only when that tile was full: every store was issued)
     // may stay in flight too
     const bool stores = tile > 0 && prev_full;
@@ -492,7 +508,9 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
   }
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the phantom pieces issued past the last tile land before the LDS is released
+#undef NT3_PHASE2_FIRST
 #undef NT3_PHASE2
+#undef NT3_PHASE2_
 #undef NT3_PHASE1
 #undef NT3_STEP_TOP
 #undef NT3_READ
