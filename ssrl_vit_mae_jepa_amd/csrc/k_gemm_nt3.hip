@@ -121,6 +121,25 @@ __device__ __forceinline__ bf16x8 row_swap8(const bf16x8& v) {
   return __builtin_bit_cast(bf16x8, x);
 }
 
+// Epilogue stores and side-input loads go through raw buffer descriptors: the address is a per-lane 32-bit offset that never changes (row in the
+// wave tile x N + column) plus a SCALAR offset (tile, 16-row group, column group), rows past M fall outside the descriptor's range and are dropped
+// (loads return zeros; the scalar offset takes part in the range check, tools/micro/buffer_range_probe.hip) -- no 64-bit address arithmetic, no
+// row compares and no exec masking in the epilogue.  Cache policy: 2 = nt, 0 = ordinary, 16 = sc1, 17 = sc0 sc1.
+constexpr int kStreamPolicy = MAE_NT3_STORE == 0 ? 2 : (MAE_NT3_STORE == 1 ? 0 : (MAE_NT3_STORE == 2 ? 16 : 17));
+template <int POLICY, class V>
+__device__ __forceinline__ void bstore16(const V& v, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_;
+  static_assert(sizeof(V) == 16, "16-byte stores only");
+  // The scalar offset is ADDED INTO the vector offset (one v_add per store) and the instruction's soffset field left at zero: with an SGPR in that
+  // field hipcc's hazard recognizer assumes that a VALU may overwrite the data registers of a 128-bit store right behind it (true on older parts),
+  // and on gfx950 the DPP move that builds the next store's data then corrupts the first dword of this one (seen in the GELU + slope epilogue:
+  // timing-dependent wrong values in dword 0 of scattered rows).
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), rs, (int)(voff + soff), 0, POLICY);
+}
+__device__ __forceinline__ bf16x8 bload16(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0));
+}
+
 // keep `keep` in the lanes whose 4-lane bank is NOT in BANKS and take `from`'s value of the lane 8 places away (row_ror:8) in the others
 template <int BANKS>
 __device__ __forceinline__ bf16x8 row_merge8(const bf16x8& keep, const bf16x8& from) {
@@ -313,6 +332,13 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
   const char* const rd_w_last = smem + G_::W_OFF + (SW - 1) * WSTG + (wn * (NI * 16) + fr) * 128;
   int c_tm = vb / tiles_n, c_tn = vb % tiles_n;   // tile being multiplied
   bool prev_full = false;
+  // epilogue addressing: descriptors over the whole (M, N) outputs / side input, two per-lane offsets that never change
+  const uint32_t out_bytes = (uint32_t)((uint64_t)M * (uint64_t)N * sizeof(TO));
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO2 = __builtin_amdgcn_make_buffer_rsrc((void*)(MODE == MAE_EPI_GELU_GRAD ? out2 : out), 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(MODE == MAE_EPI_MUL ? aux : (const void*)out), 0, (int)out_bytes, 0x00020000);
+  const uint32_t vo_one = ((uint32_t)(wm * WROWS + fr) * (uint32_t)N + (uint32_t)(wn * (NI * 16) + 4 * gb)) * (uint32_t)sizeof(TO);
+  const uint32_t vo_pair = ((uint32_t)(wm * WROWS + (fr & 7)) * (uint32_t)N + (uint32_t)(wn * (NI * 16) + 4 * gb + (fr < 8 ? 0 : 32))) * (uint32_t)sizeof(TO);
 
   auto epilogue = [&](int64_t m0, int n0, int strip) {
 #pragma unroll
@@ -326,24 +352,26 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
           acc[mi][2 * j + 1][r] = __uint_as_float(sw[1]);
         }
     const float* sbias = G_::STRIP ? reinterpret_cast<const float*>(smem + G_::BIAS_OFF + strip * (BN * 4)) + wn * (NI * 16) : bias + n0 + wn * (NI * 16);
-    const int colw = n0 + wn * (NI * 16) + 4 * gb;      // this lane's column inside group 0
+    constexpr uint32_t OSZ = sizeof(TO);
+    const uint32_t rowb = (uint32_t)N * OSZ;                                        // bytes per output row
+    const uint32_t so_tile = ((uint32_t)m0 * (uint32_t)N + (uint32_t)n0) * OSZ;      // scalar: the tile's first element (32-bit: checked by the launcher)
 #ifndef MAE_DBG_NO_EPI
     if constexpr (sizeof(TO) == 2) {
       // bf16 outputs, whole-line stores (see gemm_nt2_kernel): a lane holds 8 consecutive columns of one row; two neighbouring
       // 32-column groups that form one aligned 128-byte line go out together after the lanes of rows 0-7 and rows 8-15 swapped
       // one group's 16 bytes (DPP row_ror:8)
-      const bool lo8 = fr < 8;
+      constexpr int POL = KEEP ? 0 : kStreamPolicy, POL1 = KEEP ? 0 : (MAE_NT3_PART_STORE == 1 ? 0 : kStreamPolicy);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
-        const int64_t mrow = m0 + wm * WROWS + mi * 16;
-        const int64_t m = mrow + fr;
+        const uint32_t so = so_tile + (uint32_t)(mi * 16) * rowb;                    // scalar: this 16-row group
         bf16x8 pa[NJ], pb[TWO ? NJ : 1];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int nl = 32 * j + 4 * gb;
           f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
           if (HAS_BIAS) { b0 = load4(sbias + nl); b1 = load4(sbias + nl + 4); }
-          f32x4 v0 = acc[mi][2 * j] + b0, v1 = acc[mi][2 * j + 1] + b1;
+          f32x4 v0 = acc[mi][2 * j], v1 = acc[mi][2 * j + 1];
+          if (HAS_BIAS) { v0 += b0; v1 += b1; }   // (without a bias no add at all: x + 0.0f is not an identity the compiler may drop)
           if (MODE == MAE_EPI_GELU_GRAD || MODE == MAE_EPI_GELU_ACT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -357,45 +385,36 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
             else pa[j] = pk8(a0, a1);
           } else if (MODE == MAE_EPI_MUL) {
             f32x4 q0, q1;
-            const int64_t mc = m < M ? m : M - 1;
-            ld8(reinterpret_cast<const TO*>(aux) + mc * N + colw + 32 * j, q0, q1);
+            unpack8(bload16(rsX, vo_one, so + (uint32_t)(64 * j)), q0, q1);        // rows past M read zeros (their products are never stored)
             pa[j] = pk8(v0 * q0, v1 * q1);
           } else {
             pa[j] = pk8(v0, v1);
           }
         }
-        auto store_rows = [&](TO* __restrict__ dst, const bf16x8* pk, int ja) {
+        auto store_rows = [&](__amdgpu_buffer_rsrc_t rs, const bf16x8* pk, int ja) {
           // S1 = (rows 0-7: own group ja | rows 8-15: the partner's group ja + 1), S2 = (rows 0-7: the partner's group ja | rows 8-15: own group ja + 1):
           // one DPP move per dword with a bank mask, no selects
           const bf16x8 S1 = row_merge8<0xc>(pk[ja], pk[ja + 1]), S2 = row_merge8<0x3>(pk[ja + 1], pk[ja]);
-          const int col = colw + 32 * (lo8 ? ja : ja + 1);
-          const int64_t r1 = mrow + (fr & 7), r2 = r1 + 8;
-          if (KEEP) {
-            if (r1 < M) *reinterpret_cast<bf16x8*>(dst + r1 * N + col) = S1;
-            if (r2 < M) *reinterpret_cast<bf16x8*>(dst + r2 * N + col) = S2;
-          } else {
-            if (r1 < M) stream_store(S1, reinterpret_cast<bf16x8*>(dst + r1 * N + col));
-            if (r2 < M) stream_store(S2, reinterpret_cast<bf16x8*>(dst + r2 * N + col));
-          }
+          bstore16<POL>(S1, rs, vo_pair, so + (uint32_t)(64 * ja));
+          bstore16<POL>(S2, rs, vo_pair, so + (uint32_t)(64 * ja) + 8u * rowb);
         };
-        auto store_single = [&](TO* __restrict__ dst, const bf16x8& v, int j) {
-          if (m < M) { if (KEEP) *reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j) = v; else part_store(v, reinterpret_cast<bf16x8*>(dst + m * N + colw + 32 * j)); }
-        };
+        auto store_single = [&](__amdgpu_buffer_rsrc_t rs, const bf16x8& v, int j) { bstore16<POL1>(v, rs, vo_one, so + (uint32_t)(64 * j)); };
         if (NJ % 2 == 0) {   // the wave's columns are whole 128-byte lines (128- and 256-wide tiles)
 #pragma unroll
           for (int ja = 0; ja < NJ; ja += 2) {
-            store_rows(out, pa, ja);
-            if (TWO) store_rows(out2, pb, TWO ? ja : 0);
+            store_rows(rsO, pa, ja);
+            if (TWO) store_rows(rsO2, pb, TWO ? ja : 0);
           }
         } else if (wn == 0) {
-          store_rows(out, pa, 0); store_single(out, pa[NJ - 1], NJ - 1);
-          if (TWO) { store_rows(out2, pb, 0); store_single(out2, pb[TWO ? NJ - 1 : 0], NJ - 1); }
+          store_rows(rsO, pa, 0); store_single(rsO, pa[NJ - 1], NJ - 1);
+          if (TWO) { store_rows(rsO2, pb, 0); store_single(rsO2, pb[TWO ? NJ - 1 : 0], NJ - 1); }
         } else {
-          store_single(out, pa[0], 0); store_rows(out, pa, NJ - 2);
-          if (TWO) { store_single(out2, pb[0], 0); store_rows(out2, pb, TWO ? NJ - 2 : 0); }
+          store_single(rsO, pa[0], 0); store_rows(rsO, pa, NJ - 2);
+          if (TWO) { store_single(rsO2, pb[0], 0); store_rows(rsO2, pb, TWO ? NJ - 2 : 0); }
         }
       }
     } else {
+      constexpr int POLF = MAE_NT3_PART_STORE >= 1 ? 0 : kStreamPolicy;   // fp32 rows: two 16-byte halves per lane in two instructions (partial lines)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int nl = 32 * j + 4 * gb;
@@ -403,8 +422,11 @@ __global__ void __launch_bounds__((64 * Geo3<NI, MI, WM>::NWV), 2) gemm_nt3_kern
         if (HAS_BIAS) { b0 = load4(sbias + nl); b1 = load4(sbias + nl + 4); }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-          const int64_t m = m0 + wm * WROWS + mi * 16 + fr;
-          if (m < M) st8(reinterpret_cast<float*>(out) + m * N + colw + 32 * j, acc[mi][2 * j] + b0, acc[mi][2 * j + 1] + b1);
+          const uint32_t so = so_tile + (uint32_t)(mi * 16) * rowb + (uint32_t)(128 * j);
+          f32x4 v0 = acc[mi][2 * j], v1 = acc[mi][2 * j + 1];
+          if (HAS_BIAS) { v0 += b0; v1 += b1; }
+          bstore16<POLF>(v0, rsO, vo_one, so);
+          bstore16<POLF>(v1, rsO, vo_one, so + 16u);
         }
       }
     }
@@ -585,6 +607,7 @@ int mfma_linear_fwd_v3(const bf16* A, const bf16* W, int64_t M, int N, int K, co
   if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)e.out | (uintptr_t)e.out2 | (uintptr_t)e.bias | (uintptr_t)e.aux) & 15) != 0) return MFMA_UNSUPPORTED;
   // 32-bit byte offsets inside the buffer descriptors (a tile may start up to 255 rows before the end and reach 256 rows past it)
   if ((uint64_t)(M + 512) * (uint64_t)K * 2u >= (1ull << 32) || (uint64_t)N * (uint64_t)K * 2u >= (1ull << 32)) return MFMA_UNSUPPORTED;
+  if ((uint64_t)(M + 512) * (uint64_t)N * (e.out_dt == MAE_F32 ? 4u : 2u) >= (1ull << 32)) return MFMA_UNSUPPORTED;   // the epilogue's buffer offsets are 32-bit too
   const bool f32out = e.out_dt == MAE_F32;
   switch (e.mode) {
     case MAE_EPI_NONE: {
