@@ -293,6 +293,23 @@ def test_wgrad_buffer_dma_kernel_is_bit_identical_to_the_pointer_dma_kernel(dev,
         assert torch.equal(res[v][0], res["v3r"][0]) and torch.equal(res[v][1], res["v3r"][1]), v
 
 
+def test_wgrad_buffer_dma_32bit_offsets_at_the_top_of_their_range(dev, monkeypatch):
+    """gemm_tn4_kernel addresses dY and X with 32-bit byte offsets (descriptor per M-split); a 4.27 GB dY, 0.6 % below the limit the launcher
+    admits, gives the bits of the pointer-DMA kernel."""
+    M, N, K = 1390000, 1536, 192
+    g = torch.Generator(device=dev).manual_seed(3)
+    dY = (torch.rand(M, N, device=dev, generator=g) * 2 - 1).to(torch.bfloat16); A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    scratch = torch.zeros(lib.mae_linear_wgrad_scratch_bytes(M, N, K), dtype=torch.uint8, device=dev)
+    res = {}
+    for v in ("v3r", "v4"):
+        monkeypatch.setenv("MAE_WGRAD", v)
+        dW = torch.full((N, K), float("nan"), device=dev); db = torch.full((N,), float("nan"), device=dev)
+        check(lib.mae_linear_wgrad(_ptr(dY), _ptr(A), M, N, K, BF16, _ptr(dW), _ptr(db), _ptr(scratch), stream(dev)))
+        torch.cuda.synchronize()
+        res[v] = (dW, db)
+    assert torch.isfinite(res["v4"][0]).all() and torch.equal(res["v4"][0], res["v3r"][0]) and torch.equal(res["v4"][1], res["v3r"][1])
+
+
 @pytest.mark.parametrize("M,s0,s1", [(9000, (384, 1536), (1536, 384)), (8300, (384, 384), (1152, 384)), (8197, (192, 192), (576, 192)), (9001, (512, 1024), (1536, 512))])
 def test_wgrad_pair_buffer_dma_kernel_is_bit_identical(dev, M, s0, s1, monkeypatch):
     g = G(M + s0[0])
@@ -377,6 +394,32 @@ def test_nt3_kernel_is_bit_identical_to_nt2(dev, shape):
             assert torch.equal(outs["v2"][0], outs["v3"][0]), (epi, odt, with_bias)
             if epi == "gelu_grad":
                 assert torch.equal(outs["v2"][1], outs["v3"][1]), (epi, odt)
+    finally:
+        os.environ.pop("MAE_GEMM_NT", None)
+
+
+@pytest.mark.parametrize("M,N,K,epi,odt", [(1390000, 1536, 192, "none", BF16), (1390000, 768, 192, "none", F32), (1390001, 1536, 192, "mul", BF16)])
+def test_nt3_32bit_offsets_at_the_top_of_their_range(dev, M, N, K, epi, odt):
+    """The nt3 kernel addresses operands, outputs and side inputs with 32-bit byte offsets inside buffer descriptors (rows past M are dropped by
+    the range check).  Shapes whose last tile ends a fraction of a percent below 4 GiB: the result equals the round-2 kernel's (64-bit
+    pointers) bit for bit, and the guard rows allocated behind the output stay untouched (a wrapped or unchecked offset would land there
+    or at the start of the tensor)."""
+    import os
+    g = torch.Generator(device=dev).manual_seed(9)
+    A = (torch.rand(M, K, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
+    W = ((torch.rand(N, K, device=dev, generator=g) * 2 - 1) / K ** 0.5).to(torch.bfloat16)
+    aux = (torch.rand(M, N, device=dev, generator=g) * 4 - 2).to(torch.bfloat16) if epi == "mul" else None
+    guard = 600                                      # rows behind the tensor (a 256-row tile may start up to 255 rows before the end)
+    outs = {}
+    try:
+        for var in ("v2", "v3"):
+            os.environ["MAE_GEMM_NT"] = var
+            buf = torch.full((M + guard, N), 3.0, dtype=TDT[odt], device=dev)
+            check(lib.mae_linear_fwd(_ptr(A), _ptr(W), None, M, N, K, BF16, {"none": 0, "mul": 5}[epi], odt, _ptr(buf), None, _ptr(aux) if aux is not None else None, stream(dev)))
+            torch.cuda.synchronize()
+            assert bool((buf[M:] == 3.0).all()), var   # nothing behind row M - 1
+            outs[var] = buf[:M]
+        assert torch.isfinite(outs["v3"]).all() and torch.equal(outs["v2"], outs["v3"])
     finally:
         os.environ.pop("MAE_GEMM_NT", None)
 
